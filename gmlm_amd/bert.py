@@ -1,0 +1,124 @@
+"""BERT-geometry text encoder forward on the gfx950 kernels.
+
+Replaces the forward of HuggingFace ``BertModel`` as the reference runs it (main.py:349; classes at
+hf:modeling_bert.py:53-108 embeddings, 139-203 self-attention, 282-293 / 325-351 dense epilogues,
+354-416 layer) while keeping the HF module as the *parameter container*, so state-dict keys
+(``plm_encoder.*``), ``config.hidden_size`` and ``base_model_prefix`` stay what callers expect
+(main.py:222, 328, 380, 409).
+
+Per layer:  fused QKV GEMM (hipBLASLt) -> K5 masked attention (MFMA, per-sequence key length)
+            -> out-proj GEMM -> K6 bias+dropout+residual+LayerNorm
+            -> FFN-in GEMM -> bias+GELU(+dropout) kernel -> FFN-out GEMM -> K6.
+Also registers the attention core under HF's AttentionInterface as ``"gmlm_hip"`` so an unmodified
+HF BertModel can call K5 through ``config._attn_implementation``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.utils.checkpoint import checkpoint
+
+from . import ops
+from .nn import _linear, attention_any_dim
+
+
+def check_supported(plm) -> None:
+    cfg = plm.config
+    problems = []
+    if getattr(cfg, "model_type", None) != "bert":
+        problems.append(f"model_type={getattr(cfg, 'model_type', None)!r} (only BERT-geometry encoders are on the kernel path)")
+    if getattr(cfg, "position_embedding_type", "absolute") not in ("absolute", None):
+        problems.append("non-absolute position embeddings")
+    if getattr(cfg, "hidden_act", "gelu") != "gelu":
+        problems.append(f"hidden_act={cfg.hidden_act!r}")
+    if getattr(cfg, "is_decoder", False) or getattr(cfg, "add_cross_attention", False):
+        problems.append("decoder / cross-attention BERT")
+    if problems:
+        raise NotImplementedError("gmlm_amd text-encoder kernels do not cover this PLM: " + "; ".join(problems))
+
+
+def _layer(layer, h, lens, heads, cd, training, p_hidden, p_attn, eps):
+    att = layer.attention
+    sa = att.self
+    pdim = h.shape[-1]
+    wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
+    bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
+    qkv = _linear(h, wqkv, bqkv)                                                   # [B, L, 3P]
+    scale = (pdim // heads) ** -0.5
+    ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
+                            training)
+    so = att.output
+    a = ops.bias_res_layernorm(_linear(ctx, so.dense.weight), so.dense.bias, h, so.LayerNorm.weight, so.LayerNorm.bias, eps,
+                               False, p_hidden, training)
+    m = ops.bias_gelu(_linear(a, layer.intermediate.dense.weight), layer.intermediate.dense.bias)
+    oo = layer.output
+    return ops.bias_res_layernorm(_linear(m, oo.dense.weight), oo.dense.bias, a, oo.LayerNorm.weight, oo.LayerNorm.bias, eps,
+                                  False, p_hidden, training)
+
+
+def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtype, training: bool = False,
+                gradient_checkpointing: bool = False) -> torch.Tensor:
+    """input_ids int [B, L] (padding anywhere past ``lens[b]`` is ignored), lens int32 [B] -> [B, L, P] in ``cd``.
+
+    Token / position / type gathers are plain index gathers (bit-exact); padded key positions get
+    probability 0 in every layer, padded query rows are computed but never read by the pooling.
+    """
+    cfg = plm.config
+    emb = plm.embeddings
+    b, l = input_ids.shape
+    x = emb.word_embeddings.weight[input_ids.long()]
+    x = x + emb.token_type_embeddings.weight[0]
+    x = x + emb.position_embeddings.weight[:l].unsqueeze(0)
+    eps = cfg.layer_norm_eps
+    p_hidden = cfg.hidden_dropout_prob
+    p_attn = cfg.attention_probs_dropout_prob
+    h = ops.bias_res_layernorm(x.to(cd), None, None, emb.LayerNorm.weight, emb.LayerNorm.bias, eps, False, p_hidden, training)
+    heads = cfg.num_attention_heads
+    for layer in plm.encoder.layer:
+        if gradient_checkpointing and training and torch.is_grad_enabled():
+            h = checkpoint(_layer, layer, h, lens, heads, cd, training, p_hidden, p_attn, eps, use_reentrant=False)
+        else:
+            h = _layer(layer, h, lens, heads, cd, training, p_hidden, p_attn, eps)
+    return h
+
+
+# ---------------------------------------------------------------------------------------------
+# HF AttentionInterface registration (operator-level drop-in for K5)
+# ---------------------------------------------------------------------------------------------
+def gmlm_hip_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
+                               scaling: Optional[float] = None, **kwargs):
+    """Signature of transformers' attention functions (hf:modeling_bert.py:111-136,
+    integrations/sdpa_attention.py:79).  query/key/value: [B, h, L, d].  ``attention_mask`` must be a
+    key-padding mask (bool or additive [B,1,1|Lq,Lk]) whose valid keys form a prefix, which is what
+    tokenizer right-padding produces; returns ([B, Lq, h, d], None)."""
+    b, h, lq, d = query.shape
+    lk = key.shape[2]
+    if scaling is None:
+        scaling = d ** -0.5
+    kv_len = None
+    if attention_mask is not None:
+        m = attention_mask
+        keep = m if m.dtype == torch.bool else (m > -1.0)
+        keep = keep.reshape(b, -1, lk)[:, 0, :]
+        kv_len = keep.sum(-1).to(torch.int32)
+        # prefix check is cheap and guards against silently mis-handling arbitrary masks
+        if not bool((keep == (torch.arange(lk, device=keep.device)[None] < kv_len[:, None])).all()):
+            raise NotImplementedError("gmlm_hip attention supports right-padded key masks only")
+    to_rows = lambda t: t.transpose(1, 2).reshape(b, t.shape[2], h * d).contiguous()
+    q2, k2, v2 = to_rows(query), to_rows(key), to_rows(value)
+    if q2.dtype not in (torch.float32, torch.bfloat16):
+        q2, k2, v2 = q2.bfloat16(), k2.bfloat16(), v2.bfloat16()
+    out = attention_any_dim(q2, k2, v2, kv_len, h, scaling, dropout, dropout > 0)
+    return out.reshape(b, lq, h, d).to(query.dtype), None
+
+
+def register_hf_attention(name: str = "gmlm_hip") -> str:
+    from transformers import AttentionInterface
+    AttentionInterface.register(name, gmlm_hip_attention_forward)
+    try:  # same mask builder as sdpa (boolean / additive key-padding mask)
+        from transformers.masking_utils import AttentionMaskInterface, sdpa_mask
+        AttentionMaskInterface.register(name, sdpa_mask)
+    except Exception:  # older/newer transformers without the mask registry: eager mask is used
+        pass
+    return name

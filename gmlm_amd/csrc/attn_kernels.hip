@@ -1,0 +1,489 @@
+// K5/K7 — multi-head attention core with streaming softmax, forward + backward, gfx950 MFMA.
+// Reference: K5 = BertSelfAttention's attention call softmax(QK^T*d^-1/2 + padding mask)V
+// (hf:modeling_bert.py:188-201, eager form 111-136); K7 = CrossAttention.forward's dense
+// [1,8,N,N] softmax over all nodes (main.py:159-163).
+//
+// Design (wave64, one process per GPU, no score matrix in HBM):
+//  * forward: a workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.
+//    K/V tiles of 64 keys are staged row-major in LDS.  Scores are computed TRANSPOSED,
+//    S^T = K Q^T, with v_mfma_f32_32x32x16_bf16 (bf16) or v_mfma_f32_32x32x2_f32 (exact f32):
+//    the query column then sits on the lane and the 32 keys in the accumulator registers, so the
+//    row max / row sum are register reductions plus one half-wave exchange, the running rescale is
+//    lane-local, and the probability tile feeds the next MFMA (O^T += V^T P^T) straight from the
+//    accumulator registers as its B operand (no LDS round trip).  V^T fragments come from the same
+//    row-major LDS image through ds_read_b64_tr_b16 (hardware transpose read).
+//  * backward = three launches, no atomics (deterministic): delta = rowsum(dO*O); a dQ kernel
+//    (workgroup = 128 queries, loops over key tiles) and a dK/dV kernel (workgroup = 128 keys,
+//    loops over query tiles).  P is recomputed from Q, K and the forward's log-sum-exp.
+//  * padding: keys >= kv_len[b] get probability exactly 0 (the reference adds finfo.min and
+//    softmaxes: the same zeros in fp32); whole tiles past kv_len are skipped.
+#include "common.hpp"
+
+namespace gmlm {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define GMLM_LDS3(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+struct AttnParams {
+  const void *q, *k, *v, *out, *dout;
+  const float* lse;
+  const int32_t* kv_len;
+  float* delta;
+  void *o_w, *dq, *dk, *dv;
+  float* lse_w;
+  int64_t b, h, lq, lk;
+  int64_t q_stride, k_stride, v_stride, dq_stride, dk_stride, dv_stride;
+  float scale;
+  uint32_t drop_thresh;   // attention-probability dropout (0 = off)
+  float keep_scale;
+  uint64_t seed;
+};
+
+template <typename T> struct Pad;
+template <> struct Pad<bf16_t> { static constexpr int v = 8; };
+template <> struct Pad<float> { static constexpr int v = 4; };
+
+// ---- row fragment: D elements of one row, laid out as the "B from a row" MFMA operand -----------
+template <typename T, int D> struct RowFrag;
+template <int D> struct RowFrag<bf16_t, D> {
+  bf16x8 v[D / 16];
+  __device__ __forceinline__ void load(const bf16_t* row, bool valid, int h) {
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) {
+      if (valid) v[s] = *reinterpret_cast<const bf16x8*>(row + 16 * s + 8 * h);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[s][j] = (__bf16)0.f;
+    }
+  }
+};
+template <int D> struct RowFrag<float, D> {
+  float v[D / 2];
+  __device__ __forceinline__ void load(const float* row, bool valid, int h) {
+#pragma unroll
+    for (int s = 0; s < D / 2; ++s) v[s] = valid ? row[2 * s + h] : 0.f;
+  }
+};
+
+// acc += A(tile rows row0..row0+31, k = D) * B(frag):  result[row][col = lane's row entity]
+template <int D>
+__device__ __forceinline__ void mma_rows(const bf16_t* ts, int pitch, int row0, const RowFrag<bf16_t, D>& f, f32x16& acc,
+                                         int r, int h) {
+#pragma unroll
+  for (int s = 0; s < D / 16; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(ts + (row0 + r) * pitch + 16 * s + 8 * h);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f.v[s], acc, 0, 0, 0);
+  }
+}
+template <int D>
+__device__ __forceinline__ void mma_rows(const float* ts, int pitch, int row0, const RowFrag<float, D>& f, f32x16& acc,
+                                         int r, int h) {
+#pragma unroll
+  for (int s = 0; s < D / 2; ++s) {
+    const float a = ts[(row0 + r) * pitch + 2 * s + h];
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, f.v[s], acc, 0, 0, 0);
+  }
+}
+
+// out[db] += A(tile^T: rows = D-block db, k = tile rows row0..row0+31) * B(x)
+// x is a 32x32 accumulator tile whose ROW index is the summed index (guide: accumulator as operand).
+template <int D>
+__device__ __forceinline__ void mma_acc(const bf16_t* ts, int pitch, int row0, const f32x16& x, f32x16 (&out)[D / 32],
+                                        int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3, hh = g >> 1;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[8 * s + j];
+    const bf16_t* base = ts + (row0 + 16 * s + 4 * hh + qq) * pitch + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, base + db * 32));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, base + db * 32 + 8 * pitch));
+      bf16x8 a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+      out[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out[db], 0, 0, 0);
+    }
+  }
+}
+template <int D>
+__device__ __forceinline__ void mma_acc(const float* ts, int pitch, int row0, const f32x16& x, f32x16 (&out)[D / 32],
+                                        int lane) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int krow = row0 + (t & 3) + 8 * (t >> 2) + 4 * h;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) {
+      const float a = ts[krow * pitch + db * 32 + r];
+      out[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, x[t], out[db], 0, 0, 0);
+    }
+  }
+}
+
+// cooperative staging of ROWS rows of D elements (row-major, pitch D+pad); rows >= limit are zero
+template <typename T, int D, int ROWS, int NT>
+__device__ __forceinline__ void stage_rows(T* ts, const T* g, int64_t g_stride, int64_t row0, int64_t limit, int tid) {
+  constexpr int V = Store<T>::kVec;
+  constexpr int CPR = D / V;
+  constexpr int PITCH = D + Pad<T>::v;
+  for (int i = tid; i < ROWS * CPR; i += NT) {
+    const int row = i / CPR, c = i % CPR;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (row0 + row < limit) val = *reinterpret_cast<const uint4*>(g + (row0 + row) * g_stride + c * V);
+    *reinterpret_cast<uint4*>(ts + row * PITCH + c * V) = val;
+  }
+}
+
+// transposed epilogue store: acc holds [d-block rows (regs), entity column (lane)]
+template <typename T>
+__device__ __forceinline__ void store_t(T* rowptr /* + db*32 applied */, const f32x16& acc, float mul, int h) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    T* p = rowptr + 8 * g4 + 4 * h;
+    if constexpr (sizeof(T) == 4) {
+      *reinterpret_cast<float4*>(p) = make_float4(acc[4 * g4] * mul, acc[4 * g4 + 1] * mul, acc[4 * g4 + 2] * mul, acc[4 * g4 + 3] * mul);
+    } else {
+      uint2 w;
+      w.x = (uint32_t)f32_to_bf16(acc[4 * g4] * mul) | ((uint32_t)f32_to_bf16(acc[4 * g4 + 1] * mul) << 16);
+      w.y = (uint32_t)f32_to_bf16(acc[4 * g4 + 2] * mul) | ((uint32_t)f32_to_bf16(acc[4 * g4 + 3] * mul) << 16);
+      *reinterpret_cast<uint2*>(p) = w;
+    }
+  }
+}
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  constexpr int KT = 64, PITCH = D + Pad<T>::v, DB = D / 32;
+  __shared__ __attribute__((aligned(16))) T ks[KT * PITCH];
+  __shared__ __attribute__((aligned(16))) T vs[KT * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  const int64_t q_row = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const bool q_ok = q_row < p.lq;
+  int64_t kvlen = p.lk;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
+  const T* qg = static_cast<const T*>(p.q) + (b * p.lq + (q_ok ? q_row : 0)) * p.q_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + b * p.lk * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + b * p.lk * p.v_stride + hd * D;
+  RowFrag<T, D> qf;
+  qf.load(qg, q_ok, h);
+  f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const uint64_t drop_base = (uint64_t)((b * p.h + hd) * p.lq + q_row) * (uint64_t)p.lk;  // element (b,h,q,key) -> base + key
+  for (int64_t kv0 = 0; kv0 < kvlen; kv0 += KT) {
+    __syncthreads();
+    stage_rows<T, D, KT, 256>(ks, kg, p.k_stride, kv0, p.lk, tid);
+    stage_rows<T, D, KT, 256>(vs, vg, p.v_stride, kv0, p.lk, tid);
+    __syncthreads();
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+      mma_rows<D>(ks, PITCH, kb * 32, qf, s[kb], r, h);
+    }
+    float rmax = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t key = kv0 + kb * 32 + acc_row(i, h);
+        const float v = key < kvlen ? s[kb][i] * p.scale : -INFINITY;
+        s[kb][i] = v;
+        rmax = fmaxf(rmax, v);
+      }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    const float m_new = fmaxf(m, rmax);            // finite: key kv0 is always valid
+    const float alpha = __expf(m - m_new);         // m = -inf -> 0
+    float rsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float e = __expf(s[kb][i] - m_new);  // masked -> exp(-inf) = 0
+        rsum += e;                                 // the normaliser uses the un-dropped probabilities
+        s[kb][i] = p.drop_thresh ? e * dropout_scale(p.seed, drop_base + (uint64_t)(kv0 + kb * 32 + acc_row(i, h)), p.drop_thresh, p.keep_scale) : e;
+      }
+    rsum += __shfl_xor(rsum, 32, 64);
+    l = l * alpha + rsum;
+    m = m_new;
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) mma_acc<D>(vs, PITCH, kb * 32, s[kb], o, lane);
+  }
+  if (q_ok) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    T* og = static_cast<T*>(p.o_w) + ((b * p.lq + q_row) * p.h + hd) * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
+    if (h == 0 && p.lse_w) p.lse_w[(b * p.h + hd) * p.lq + q_row] = l > 0.f ? m + __logf(l) : -INFINITY;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: delta[b,h,q] = sum_d dO * O
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, int64_t rows /* b*lq*h */, int d,
+                                  int64_t lq, int64_t hn, float* __restrict__ delta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h) flat, matches o layout
+  if (i >= rows) return;
+  constexpr int V = Store<T>::kVec;
+  float acc = 0.f;
+  for (int c = 0; c < d / V; ++c) {
+    float a[V], g[V];
+    Store<T>::ldv(o + i * d + c * V, a);
+    Store<T>::ldv(dout + i * d + c * V, g);
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc += a[v] * g[v];
+  }
+  const int64_t hd = i % hn, bq = i / hn, q = bq % lq, b = bq / lq;
+  delta[(b * hn + hd) * lq + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dQ.  workgroup = 128 queries, loop over key tiles of 32.
+//   S^T = K Q^T, P^T = exp(scale*S^T - lse[q]), dP^T = V dO^T, dS^T = P^T*(dP^T - delta[q]),
+//   dQ^T += K^T dS^T  (all with the query on the lane)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr int KT = 32, PITCH = D + Pad<T>::v, DB = D / 32;
+  __shared__ __attribute__((aligned(16))) T ks[KT * PITCH];
+  __shared__ __attribute__((aligned(16))) T vs[KT * PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  const int64_t q_row = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const bool q_ok = q_row < p.lq;
+  int64_t kvlen = p.lk;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
+  const int64_t qr = q_ok ? q_row : 0;
+  const T* kg = static_cast<const T*>(p.k) + b * p.lk * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + b * p.lk * p.v_stride + hd * D;
+  RowFrag<T, D> qf, dof;
+  qf.load(static_cast<const T*>(p.q) + (b * p.lq + qr) * p.q_stride + hd * D, q_ok, h);
+  dof.load(static_cast<const T*>(p.dout) + ((b * p.lq + qr) * p.h + hd) * D, q_ok, h);
+  const float lse = q_ok ? p.lse[(b * p.h + hd) * p.lq + q_row] : 0.f;
+  const float dl = q_ok ? p.delta[(b * p.h + hd) * p.lq + q_row] : 0.f;
+  const uint64_t drop_base = (uint64_t)((b * p.h + hd) * p.lq + q_row) * (uint64_t)p.lk;
+  f32x16 dq[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+  for (int64_t kv0 = 0; kv0 < kvlen; kv0 += KT) {
+    __syncthreads();
+    stage_rows<T, D, KT, 256>(ks, kg, p.k_stride, kv0, p.lk, tid);
+    stage_rows<T, D, KT, 256>(vs, vg, p.v_stride, kv0, p.lk, tid);
+    __syncthreads();
+    f32x16 s, dp;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+    mma_rows<D>(ks, PITCH, 0, qf, s, r, h);
+    mma_rows<D>(vs, PITCH, 0, dof, dp, r, h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int64_t key = kv0 + acc_row(i, h);
+      const float pr = (key < kvlen && q_ok) ? __expf(s[i] * p.scale - lse) : 0.f;
+      const float ms = p.drop_thresh ? dropout_scale(p.seed, drop_base + (uint64_t)key, p.drop_thresh, p.keep_scale) : 1.f;
+      s[i] = pr * (dp[i] * ms - dl);
+    }
+    mma_acc<D>(ks, PITCH, 0, s, dq, lane);
+  }
+  if (q_ok) {
+    T* og = static_cast<T*>(p.dq) + (b * p.lq + q_row) * p.dq_stride + hd * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, dq[d], p.scale, h);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward: dK, dV.  workgroup = 128 keys (32 per wave), loop over query tiles of 32.
+//   S = Q K^T, P = exp(scale*S - lse[q]), dV^T += dO^T P, dP = dO V^T, dS = P*(dP - delta[q]),
+//   dK^T += Q^T dS   (all with the key on the lane, the query in the accumulator registers)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr int QT = 32, PITCH = D + Pad<T>::v, DB = D / 32;
+  __shared__ __attribute__((aligned(16))) T qs[QT * PITCH];
+  __shared__ __attribute__((aligned(16))) T dos[QT * PITCH];
+  __shared__ float lse_s[QT];
+  __shared__ float dl_s[QT];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  int64_t kvlen = p.lk;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
+  const int64_t key = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const bool key_in = key < p.lk;           // row exists in memory
+  const bool key_ok = key < kvlen;          // takes part in the softmax
+  const int64_t kr = key_in ? key : 0;
+  RowFrag<T, D> kf, vf;
+  kf.load(static_cast<const T*>(p.k) + (b * p.lk + kr) * p.k_stride + hd * D, key_in, h);
+  vf.load(static_cast<const T*>(p.v) + (b * p.lk + kr) * p.v_stride + hd * D, key_in, h);
+  const T* qg = static_cast<const T*>(p.q) + b * p.lq * p.q_stride + hd * D;
+  const T* dog = static_cast<const T*>(p.dout) + (b * p.lq * p.h + hd) * D;
+  f32x16 dk[DB], dv[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+  // a whole workgroup past kv_len has nothing to accumulate (block-uniform condition)
+  const bool block_live = (int64_t)blockIdx.x * 128 < kvlen;
+  if (block_live) {
+    for (int64_t q0 = 0; q0 < p.lq; q0 += QT) {
+      __syncthreads();
+      stage_rows<T, D, QT, 256>(qs, qg, p.q_stride, q0, p.lq, tid);
+      stage_rows<T, D, QT, 256>(dos, dog, p.h * D, q0, p.lq, tid);
+      if (tid < QT) {
+        const bool ok = q0 + tid < p.lq;
+        lse_s[tid] = ok ? p.lse[(b * p.h + hd) * p.lq + q0 + tid] : 0.f;
+        dl_s[tid] = ok ? p.delta[(b * p.h + hd) * p.lq + q0 + tid] : 0.f;
+      }
+      __syncthreads();
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      mma_rows<D>(qs, PITCH, 0, kf, s, r, h);
+      mma_rows<D>(dos, PITCH, 0, vf, dp, r, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qi = acc_row(i, h);
+        const float pr = (key_ok && q0 + qi < p.lq) ? __expf(s[i] * p.scale - lse_s[qi]) : 0.f;
+        const float ms = p.drop_thresh ? dropout_scale(p.seed, (uint64_t)((b * p.h + hd) * p.lq + q0 + qi) * (uint64_t)p.lk + (uint64_t)key, p.drop_thresh, p.keep_scale) : 1.f;
+        s[i] = pr * ms;
+        dp[i] = pr * (dp[i] * ms - dl_s[qi]);
+      }
+      mma_acc<D>(dos, PITCH, 0, s, dv, lane);
+      mma_acc<D>(qs, PITCH, 0, dp, dk, lane);
+    }
+  }
+  if (key_in) {
+    T* dkg = static_cast<T*>(p.dk) + (b * p.lk + key) * p.dk_stride + hd * D;
+    T* dvg = static_cast<T*>(p.dv) + (b * p.lk + key) * p.dv_stride + hd * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      store_t<T>(dkg + d * 32, dk[d], p.scale, h);
+      store_t<T>(dvg + d * 32, dv[d], 1.f, h);
+    }
+  }
+}
+
+static int attn_check(const char* who, int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d, int dtype) {
+  GMLM_REQUIRE(b >= 0 && h > 0 && lq >= 0 && lk >= 0, "%s: bad sizes", who);
+  GMLM_REQUIRE(d == 64 || d == 96, "%s: head dim %ld not supported (64 or 96)", who, (long)d);
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "%s: unsupported dtype", who);
+  GMLM_REQUIRE(b * h <= 65535, "%s: batch*heads %ld > 65535", who, (long)(b * h));
+  return GMLM_OK;
+}
+static int stride_check(const char* who, const void* ptr, int64_t stride, int64_t min_stride, int dtype) {
+  const int v = dtype == GMLM_F32 ? 4 : 8;
+  GMLM_REQUIRE(ptr && aligned16(ptr), "%s: null or not 16-byte aligned pointer", who);
+  GMLM_REQUIRE(stride >= min_stride && stride % v == 0, "%s: row stride %ld must be >= %ld and a multiple of %d", who,
+               (long)stride, (long)min_stride, v);
+  return GMLM_OK;
+}
+
+}  // namespace gmlm
+
+using namespace gmlm;
+
+#define GMLM_ATTN_DISPATCH(KERNEL, grid, st, prm)                                   \
+  do {                                                                              \
+    if (dtype == GMLM_BF16) {                                                       \
+      if (d == 64) KERNEL<bf16_t, 64><<<grid, 256, 0, st>>>(prm);                   \
+      else KERNEL<bf16_t, 96><<<grid, 256, 0, st>>>(prm);                           \
+    } else {                                                                        \
+      if (d == 64) KERNEL<float, 64><<<grid, 256, 0, st>>>(prm);                    \
+      else KERNEL<float, 96><<<grid, 256, 0, st>>>(prm);                            \
+    }                                                                               \
+  } while (0)
+
+extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
+                                  int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
+                                  float scale, float dropout_p, uint64_t seed, void* out, float* lse, int dtype,
+                                  gmlm_stream_t stream) {
+  int rc = attn_check("attention_fwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_fwd: dropout_p must be in [0,1)");
+  if (rc != GMLM_OK) return rc;
+  if (b == 0 || lq == 0) return GMLM_OK;
+  if ((rc = stride_check("attention_fwd(q)", q, q_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if (lk > 0) {
+    if ((rc = stride_check("attention_fwd(k)", k, k_stride, h * d, dtype)) != GMLM_OK) return rc;
+    if ((rc = stride_check("attention_fwd(v)", v, v_stride, h * d, dtype)) != GMLM_OK) return rc;
+  }
+  GMLM_REQUIRE(out && aligned16(out), "attention_fwd: null or misaligned out");
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.lse_w = lse;
+  p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
+  p.scale = scale;
+  p.drop_thresh = dropout_threshold(dropout_p); p.keep_scale = 1.f / (1.f - dropout_p); p.seed = seed;
+  dim3 grid((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+  hipStream_t st = as_stream(stream);
+  GMLM_ATTN_DISPATCH(attn_fwd_kernel, grid, st, p);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d) {
+  (void)lk; (void)d;
+  return (size_t)(b * h * lq > 0 ? b * h * lq : 1) * sizeof(float);  // delta
+}
+
+extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                  const float* lse, const int32_t* kv_len, int64_t b, int64_t h, int64_t lq, int64_t lk,
+                                  int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
+                                  float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, int dtype,
+                                  void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
+  int rc = attn_check("attention_bwd", b, h, lq, lk, d, dtype);
+  if (rc != GMLM_OK) return rc;
+  if (b == 0 || (lq == 0 && lk == 0)) return GMLM_OK;
+  GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_bwd: dropout_p must be in [0,1)");
+  GMLM_REQUIRE(lq > 0 && lk > 0, "attention_bwd: empty query or key set with a non-empty counterpart is not supported");
+  if ((rc = stride_check("attention_bwd(q)", q, q_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if ((rc = stride_check("attention_bwd(k)", k, k_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if ((rc = stride_check("attention_bwd(v)", v, v_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if ((rc = stride_check("attention_bwd(dq)", dq, dq_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if ((rc = stride_check("attention_bwd(dk)", dk, dk_stride, h * d, dtype)) != GMLM_OK) return rc;
+  if ((rc = stride_check("attention_bwd(dv)", dv, dv_stride, h * d, dtype)) != GMLM_OK) return rc;
+  GMLM_REQUIRE(out && dout && lse && aligned16(out) && aligned16(dout), "attention_bwd: null or misaligned out/dout/lse");
+  GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_attention_bwd_workspace_bytes(b, h, lq, lk, d),
+               "attention_bwd: workspace too small");
+  hipStream_t st = as_stream(stream);
+  AttnParams p{};
+  p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = lse; p.kv_len = kv_len;
+  p.delta = static_cast<float*>(workspace);
+  p.dq = dq; p.dk = dk; p.dv = dv;
+  p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
+  p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
+  p.drop_thresh = dropout_threshold(dropout_p); p.keep_scale = 1.f / (1.f - dropout_p); p.seed = seed;
+  const int64_t rows = b * lq * h;
+  if (dtype == GMLM_BF16)
+    attn_delta_kernel<bf16_t><<<(int)cdiv(rows, 256), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)dout, rows, (int)d, lq, h, p.delta);
+  else
+    attn_delta_kernel<float><<<(int)cdiv(rows, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
+  GMLM_LAUNCH_CHECK();
+  dim3 gq((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+  GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, gq, st, p);
+  GMLM_LAUNCH_CHECK();
+  dim3 gk((unsigned)cdiv(lk, 128), (unsigned)(b * h));
+  GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, st, p);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}

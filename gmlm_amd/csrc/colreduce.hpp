@@ -1,0 +1,101 @@
+// Deterministic column reduction over the rows of a row-major [n, f] problem (gfx950).
+//   out[k][c] = sum_i fn(i, c)[k],  k < K
+// Pass 1: block (column tile of 64, row chunk) -> partial[chunk][k][c]; each wave reads 64
+// consecutive elements of one row per step (coalesced), 4 rows in flight per block.
+// Pass 2: partial chunks summed in chunk order.  No atomics => bitwise reproducible.
+#pragma once
+#include "common.hpp"
+
+namespace gmlm {
+
+struct ColReducePlan {
+  int col_tiles;
+  int chunks;
+  int64_t rows_per_chunk;
+};
+
+inline ColReducePlan col_reduce_plan(int64_t n, int64_t f) {
+  ColReducePlan p;
+  p.col_tiles = (int)cdiv(f, 64);
+  int64_t chunks = cdiv(4096, p.col_tiles);       // aim for ~4096 blocks
+  const int64_t max_chunks = cdiv(n, 16);          // at least 16 rows per chunk
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  p.rows_per_chunk = cdiv(n, chunks);
+  p.chunks = (int)cdiv(n, p.rows_per_chunk);
+  if (p.chunks < 1) p.chunks = 1;
+  return p;
+}
+
+inline size_t col_reduce_workspace_bytes(int64_t n, int64_t f, int k) {
+  ColReducePlan p = col_reduce_plan(n, f);
+  return (size_t)p.chunks * k * f * sizeof(float);
+}
+
+template <int K, typename Fn>
+__global__ __launch_bounds__(256) void col_reduce_partial_kernel(int64_t n, int64_t f, int64_t rows_per_chunk, Fn fn,
+                                                                  float* __restrict__ partial) {
+  __shared__ float red[4][K][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  float acc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  if (c < f) {
+    for (int64_t r = r0 + ty; r < r1; r += 4) {
+      float v[K];
+      fn(r, c, v);
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc[k] += v[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) red[ty][k][tx] = acc[k];
+  __syncthreads();
+  if (ty == 0 && c < f) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      partial[((int64_t)blockIdx.y * K + k) * f + c] = (red[0][k][tx] + red[1][k][tx]) + (red[2][k][tx] + red[3][k][tx]);
+  }
+}
+
+template <int K>
+__global__ void col_reduce_final_kernel(const float* __restrict__ partial, int chunks, int64_t f, float* __restrict__ out,
+                                        float scale) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= f) return;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    float s = 0.f;
+    for (int j = 0; j < chunks; ++j) s += partial[((int64_t)j * K + k) * f + c];
+    out[(int64_t)k * f + c] = s * scale;
+  }
+}
+
+// out: [K, f] (k-major).  Returns a gmlm status.
+template <int K, typename Fn>
+int col_reduce(int64_t n, int64_t f, Fn fn, float* out, void* workspace, size_t workspace_bytes, hipStream_t st,
+               float scale = 1.f) {
+  if (f <= 0) return GMLM_OK;
+  if (n <= 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * K * f, st);
+    if (e != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(e)); return GMLM_ELAUNCH; }
+    return GMLM_OK;
+  }
+  const ColReducePlan p = col_reduce_plan(n, f);
+  if (workspace_bytes < (size_t)p.chunks * K * f * sizeof(float) || !workspace) {
+    set_error("column reduction: workspace too small (%zu < %zu)", workspace_bytes, (size_t)p.chunks * K * f * sizeof(float));
+    return GMLM_EWORKSPACE;
+  }
+  float* partial = static_cast<float*>(workspace);
+  col_reduce_partial_kernel<K, Fn><<<dim3(p.col_tiles, p.chunks), 256, 0, st>>>(n, f, p.rows_per_chunk, fn, partial);
+  GMLM_LAUNCH_CHECK();
+  col_reduce_final_kernel<K><<<(int)cdiv(f, 256), 256, 0, st>>>(partial, p.chunks, f, out, scale);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+}  // namespace gmlm

@@ -1,0 +1,136 @@
+// Internal helpers shared by the gfx950 kernels of libgmlm_hip.so (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/gmlm_hip.h"
+
+namespace gmlm {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define GMLM_REQUIRE(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::gmlm::set_error(__VA_ARGS__);      \
+      return GMLM_EINVAL;                  \
+    }                                      \
+  } while (0)
+
+#define GMLM_HIP(expr)                                                                  \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      ::gmlm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GMLM_ELAUNCH;                                                              \
+    }                                                                                   \
+  } while (0)
+
+#define GMLM_LAUNCH_CHECK()                                                             \
+  do {                                                                                  \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e != hipSuccess) {                                                             \
+      ::gmlm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return GMLM_ELAUNCH;                                                              \
+    }                                                                                   \
+  } while (0)
+
+inline hipStream_t as_stream(gmlm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+// memory-bound grid cap: 256 CUs x 8 blocks (guide G11), grid-stride the rest
+inline int grid_cap(int64_t blocks, int64_t cap = 2048) { return (int)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks)); }
+
+// ---- storage types -------------------------------------------------------------------------
+using bf16_t = uint16_t;  // raw bits; converted with the helpers below
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  // plain cast path keeps NaN a NaN (v_cvt_pk_bf16_f32 on gfx950)
+  __hip_bfloat16 b = __float2bfloat16(f);
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+
+template <typename T> struct Store;
+template <> struct Store<float> {
+  static constexpr int kVec = 4;  // elements per 16 bytes
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ void ldv(const float* p, float (&o)[4]) {
+    float4 v = *reinterpret_cast<const float4*>(p);
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[4]) {
+    o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+  }
+  __device__ static __forceinline__ void stv(float* p, const float (&o)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+};
+template <> struct Store<bf16_t> {
+  static constexpr int kVec = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ static __forceinline__ void ldv(const bf16_t* p, float (&o)[8]) {
+    unpack(*reinterpret_cast<const uint4*>(p), o);
+  }
+  __device__ static __forceinline__ void unpack(const uint4& v, float (&o)[8]) {
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      o[2 * i] = __uint_as_float(w[i] << 16);
+      o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+  }
+  __device__ static __forceinline__ void stv(bf16_t* p, const float (&o)[8]) {
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+  }
+};
+
+// ---- wave64 reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- replayable dropout mask: counter hash of (seed, element index) ---------------------------
+// splitmix64-style finaliser; the same (seed, idx) gives the same decision in forward, in the
+// checkpoint recompute and in backward, so no mask tensor is stored.
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((z ^ (z >> 31)) >> 32);
+}
+// returns the multiplier applied to a kept / dropped element
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float keep_scale) {
+  return hash_u32(seed, idx) >= thresh ? keep_scale : 0.f;
+}
+inline uint32_t dropout_threshold(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+}  // namespace gmlm

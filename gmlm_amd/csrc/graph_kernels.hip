@@ -1,0 +1,201 @@
+// K1 — degree, degree-bucket edge typing, relation-segmented CSR build (integer, bit-exact).
+// Reference: torch_geometric.utils.degree (main.py:65,256), bucketing loop main.py:257-267,
+// RGCNConv per-relation edge compaction (call sites main.py:272-308).
+//
+// The graph is static across training steps, so all of this runs once per graph (GraphCache on the
+// host side).  The stable sort uses rocPRIM's radix sort (a one-off setup op, not a hot kernel);
+// everything else is a plain grid-stride kernel: 8-byte coalesced reads of edge_index, int atomics
+// only for the degree histogram (integer adds are order-independent => bit-exact).
+#include "common.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace gmlm {
+
+__global__ void degree_kernel(const int64_t* __restrict__ index, int64_t e, int64_t n, int32_t* __restrict__ deg) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = index[i];
+    if (v >= 0 && v < n) atomicAdd(&deg[v], 1);
+  }
+}
+
+__global__ void i32_to_f32_kernel(const int32_t* __restrict__ a, int64_t n, float* __restrict__ o) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    o[i] = (float)a[i];
+}
+
+__global__ void edge_bucket_kernel(const int64_t* __restrict__ src, const int32_t* __restrict__ deg, int64_t e,
+                                   int64_t* __restrict__ edge_type) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t d = deg[src[i]];
+    edge_type[i] = d <= 2 ? 0 : (d <= 5 ? 1 : (d <= 10 ? 2 : 3));
+  }
+}
+
+__global__ void rel_hist_kernel(const int64_t* __restrict__ edge_type, int64_t e, int r, int32_t* __restrict__ cnt) {
+  __shared__ int32_t local[64];
+  if (threadIdx.x < 64) local[threadIdx.x] = 0;
+  __syncthreads();
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = edge_type[i];
+    if (t >= 0 && t < r) atomicAdd(&local[t], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x < r && local[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], local[threadIdx.x]);
+}
+
+__global__ void make_keys_kernel(const int64_t* __restrict__ node, const int64_t* __restrict__ rel,
+                                 const int32_t* __restrict__ remap, int r_active, int64_t e, int64_t num_segments,
+                                 int32_t* __restrict__ keys, int32_t* __restrict__ iota, int32_t* __restrict__ bad) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t k = node[i] * r_active;
+    if (rel) {
+      const int32_t m = remap[rel[i]];
+      if (m < 0) { *bad = 1; k = 0; } else k += m;
+    }
+    if (k < 0 || k >= num_segments) { *bad = 2; k = 0; }
+    keys[i] = (int32_t)k;
+    iota[i] = (int32_t)i;
+  }
+}
+
+// rowptr[s] = first position t whose sorted key >= s.  Thread t owns the gap (key[t-1], key[t]].
+__global__ void rowptr_fill_kernel(const int32_t* __restrict__ sorted_keys, int64_t e, int64_t num_segments,
+                                   int32_t* __restrict__ rowptr) {
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t <= e; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t lo = t == 0 ? -1 : sorted_keys[t - 1];
+    const int64_t hi = t == e ? num_segments : sorted_keys[t];
+    for (int64_t s = lo + 1; s <= hi; ++s) rowptr[s] = (int32_t)t;
+  }
+}
+
+template <typename S>
+__global__ void gather_kernel(const S* __restrict__ src, const int32_t* __restrict__ perm, int64_t e,
+                              int32_t* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = (int32_t)src[perm[i]];
+}
+
+__global__ void inv_count_kernel(const int32_t* __restrict__ rowptr, int64_t s, float* __restrict__ inv) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < s; i += (int64_t)gridDim.x * blockDim.x) {
+    const int32_t c = rowptr[i + 1] - rowptr[i];
+    inv[i] = 1.f / (float)(c > 1 ? c : 1);
+  }
+}
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static size_t sort_temp_bytes(int64_t e) {
+  size_t tmp = 0;
+  int32_t* nk = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, nk, nk, nk, nk, (size_t)(e > 0 ? e : 1), 0, 32, (hipStream_t)0);
+  return tmp;
+}
+
+}  // namespace gmlm
+
+using namespace gmlm;
+
+extern "C" int gmlm_degree_i32(const int64_t* index, int64_t e, int64_t n, int32_t* deg, gmlm_stream_t stream) {
+  GMLM_REQUIRE(n >= 0 && e >= 0 && (n == 0 || deg) && (e == 0 || index), "degree: bad arguments (n=%ld e=%ld)", (long)n, (long)e);
+  GMLM_REQUIRE(n < (1ll << 31), "degree: n=%ld exceeds int32 range", (long)n);
+  if (n == 0) return GMLM_OK;
+  GMLM_HIP(hipMemsetAsync(deg, 0, sizeof(int32_t) * n, as_stream(stream)));
+  if (e == 0) return GMLM_OK;
+  degree_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(index, e, n, deg);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_degree_f32(const int64_t* index, int64_t e, int64_t n, float* deg, gmlm_stream_t stream) {
+  // counts accumulate as int32 in place (same bytes), then convert: exact for counts < 2^24 like the
+  // reference's float32 scatter_add of ones; above that the reference itself saturates.
+  int rc = gmlm_degree_i32(index, e, n, reinterpret_cast<int32_t*>(deg), stream);
+  if (rc != GMLM_OK || n == 0) return rc;
+  i32_to_f32_kernel<<<grid_cap(cdiv(n, 256)), 256, 0, as_stream(stream)>>>(reinterpret_cast<int32_t*>(deg), n, deg);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_edge_bucket(const int64_t* src, const int32_t* deg, int64_t e, int64_t* edge_type,
+                                gmlm_stream_t stream) {
+  GMLM_REQUIRE(e >= 0 && (e == 0 || (src && deg && edge_type)), "edge_bucket: bad arguments");
+  if (e == 0) return GMLM_OK;
+  edge_bucket_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(src, deg, e, edge_type);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_relation_histogram(const int64_t* edge_type, int64_t e, int num_relations, int32_t* rel_count,
+                                       gmlm_stream_t stream) {
+  GMLM_REQUIRE(num_relations > 0 && num_relations <= 64 && rel_count && (e == 0 || edge_type),
+               "relation_histogram: num_relations must be in [1, 64]");
+  GMLM_HIP(hipMemsetAsync(rel_count, 0, sizeof(int32_t) * num_relations, as_stream(stream)));
+  if (e == 0) return GMLM_OK;
+  rel_hist_kernel<<<grid_cap(cdiv(e, 256), 1024), 256, 0, as_stream(stream)>>>(edge_type, e, num_relations, rel_count);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" size_t gmlm_segment_sort_workspace_bytes(int64_t e) {
+  const size_t n = (size_t)(e > 0 ? e : 1);
+  // [iota | sorted_keys | unsorted keys (when caller passes keys == NULL) | rocprim temp]
+  return 3 * align256(n * sizeof(int32_t)) + align256(sort_temp_bytes(e));
+}
+
+extern "C" int gmlm_segment_sort(const int64_t* node, const int64_t* rel, const int32_t* rel_remap, int r_active,
+                                 int64_t e, int64_t num_segments, int32_t* keys, int32_t* perm, int32_t* rowptr,
+                                 int32_t* bad_flag, void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
+  GMLM_REQUIRE(e >= 0 && num_segments >= 0 && r_active >= 1 && rowptr && bad_flag, "segment_sort: bad arguments");
+  GMLM_REQUIRE(e == 0 || (node && perm && workspace), "segment_sort: null pointer");
+  GMLM_REQUIRE(!rel || rel_remap, "segment_sort: rel given without rel_remap");
+  GMLM_REQUIRE(num_segments < (1ll << 31) - 1 && e < (1ll << 31) - 1, "segment_sort: int32 index range exceeded");
+  GMLM_REQUIRE(workspace_bytes >= gmlm_segment_sort_workspace_bytes(e), "segment_sort: workspace too small");
+  hipStream_t st = as_stream(stream);
+  GMLM_HIP(hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st));
+  if (e == 0) {
+    GMLM_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (num_segments + 1), st));
+    return GMLM_OK;
+  }
+  char* ws = static_cast<char*>(workspace);
+  const size_t slot = align256((size_t)e * sizeof(int32_t));
+  int32_t* iota = reinterpret_cast<int32_t*>(ws);
+  int32_t* sorted_keys = reinterpret_cast<int32_t*>(ws + slot);
+  int32_t* ukeys = keys ? keys : reinterpret_cast<int32_t*>(ws + 2 * slot);
+  void* tmp = ws + 3 * slot;
+  size_t tmp_bytes = workspace_bytes - 3 * slot;
+  make_keys_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, st>>>(node, rel, rel_remap, r_active, e, num_segments, ukeys, iota,
+                                                            bad_flag);
+  GMLM_LAUNCH_CHECK();
+  int end_bit = 1;
+  while (end_bit < 32 && (1ll << end_bit) < num_segments) ++end_bit;
+  GMLM_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, ukeys, sorted_keys, iota, perm, (size_t)e, 0, end_bit, st));
+  rowptr_fill_kernel<<<grid_cap(cdiv(e + 1, 256)), 256, 0, st>>>(sorted_keys, e, num_segments, rowptr);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_gather_i64_to_i32(const int64_t* src, const int32_t* perm, int64_t e, int32_t* out,
+                                      gmlm_stream_t stream) {
+  GMLM_REQUIRE(e >= 0 && (e == 0 || (src && perm && out)), "gather: bad arguments");
+  if (e == 0) return GMLM_OK;
+  gather_kernel<int64_t><<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(src, perm, e, out);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_gather_i32(const int32_t* src, const int32_t* perm, int64_t e, int32_t* out, gmlm_stream_t stream) {
+  GMLM_REQUIRE(e >= 0 && (e == 0 || (src && perm && out)), "gather: bad arguments");
+  if (e == 0) return GMLM_OK;
+  gather_kernel<int32_t><<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(src, perm, e, out);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_segment_inv_count(const int32_t* rowptr, int64_t num_segments, float* inv_cnt, gmlm_stream_t stream) {
+  GMLM_REQUIRE(num_segments >= 0 && (num_segments == 0 || (rowptr && inv_cnt)), "segment_inv_count: bad arguments");
+  if (num_segments == 0) return GMLM_OK;
+  inv_count_kernel<<<grid_cap(cdiv(num_segments, 256)), 256, 0, as_stream(stream)>>>(rowptr, num_segments, inv_cnt);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}

@@ -1,0 +1,231 @@
+// K8 masked mean pooling + row scatter (main.py:351-358), K9 soft-mask row blend (main.py:92-99),
+// bias+GELU(+dropout) elementwise (hf:modeling_bert.py:333-336, main.py:245).  HBM-bound streaming
+// kernels: thread <-> column, rows stream through, coalesced; reductions have a fixed order.
+#include "colreduce.hpp"
+
+namespace gmlm {
+
+// block (b, column tile of 256): out[node_idx[b], c] = sum_{t < len[b]} hs[b, t, c] / max(len, 1e-9)
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__ hs, const int32_t* __restrict__ len,
+                                                            const int64_t* __restrict__ node_idx, int64_t l, int64_t p,
+                                                            float* __restrict__ out) {
+  const int64_t b = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= p) return;
+  int n = len[b];
+  if (n > l) n = (int)l;
+  const T* base = hs + b * l * p + c;
+  float acc = 0.f;
+  for (int t = 0; t < n; ++t) acc += Store<T>::ld(base + (int64_t)t * p);
+  out[node_idx[b] * p + c] = acc / fmaxf((float)n, 1e-9f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ len,
+                                                            const int64_t* __restrict__ node_idx, int64_t l, int64_t p,
+                                                            T* __restrict__ dhs) {
+  const int64_t b = blockIdx.y;
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= p) return;
+  int n = len[b];
+  if (n > l) n = (int)l;
+  const float g = dout[node_idx[b] * p + c] / fmaxf((float)n, 1e-9f);
+  T* base = dhs + b * l * p + c;
+  for (int64_t t = 0; t < l; ++t) Store<T>::st(base + t * p, t < n ? g : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmask_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                            const float* __restrict__ tok, float beta, int64_t n, int64_t f,
+                                                            T* __restrict__ out, int64_t out_stride) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= out_stride) return;
+  const float tk = c < f ? beta * tok[c] : 0.f;
+  const float om = 1.f - beta;
+  for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
+    float v = 0.f;                                   // columns [f, out_stride) are zero padding
+    if (c < f) {
+      v = x[r * f + c];
+      if (mask[r]) v = om * v + tk;
+    }
+    Store<T>::st(out + r * out_stride + c, v);
+  }
+}
+
+struct SoftmaskBwdFn {
+  const float* dout;
+  int64_t stride;
+  const uint8_t* mask;
+  __device__ void operator()(int64_t r, int64_t c, float (&v)[1]) const { v[0] = mask[r] ? dout[r * stride + c] : 0.f; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
+                                                             int64_t rows, int64_t f, uint32_t thresh, float keep_scale,
+                                                             uint64_t seed, T* __restrict__ y) {
+  constexpr int V = Store<T>::kVec;
+  const int64_t nch = f / V;
+  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ch >= nch) return;
+  float bv[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) bv[v] = bias ? bias[ch * V + v] : 0.f;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t off = r * f + ch * V;
+    float a[V];
+    Store<T>::ldv(x + off, a);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      a[v] = gelu_erf(a[v] + bv[v]);
+      if (thresh) a[v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
+    }
+    Store<T>::stv(y + off, a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ bias, int64_t rows, int64_t f,
+                                                             uint32_t thresh, float keep_scale, uint64_t seed,
+                                                             T* __restrict__ dx) {
+  constexpr int V = Store<T>::kVec;
+  const int64_t nch = f / V;
+  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ch >= nch) return;
+  float bv[V];
+#pragma unroll
+  for (int v = 0; v < V; ++v) bv[v] = bias ? bias[ch * V + v] : 0.f;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t off = r * f + ch * V;
+    float a[V], g[V];
+    Store<T>::ldv(x + off, a);
+    Store<T>::ldv(dy + off, g);
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      if (thresh) g[v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
+      g[v] *= gelu_erf_grad(a[v] + bv[v]);
+    }
+    Store<T>::stv(dx + off, g);
+  }
+}
+
+template <typename T>
+struct ColSumFn {
+  const T* a;
+  int64_t f;
+  __device__ void operator()(int64_t r, int64_t c, float (&v)[1]) const { v[0] = Store<T>::ld(a + r * f + c); }
+};
+
+static inline dim3 stream_grid(int64_t rows, int64_t cols_units) {
+  const int ct = (int)cdiv(cols_units, 256);
+  int64_t ry = cdiv(4096, ct);
+  if (ry > rows) ry = rows;
+  if (ry < 1) ry = 1;
+  return dim3(ct, (unsigned)ry);
+}
+
+}  // namespace gmlm
+
+using namespace gmlm;
+
+extern "C" int gmlm_meanpool_scatter_fwd(const void* hs, const int32_t* len, const int64_t* node_idx, int64_t b, int64_t l,
+                                         int64_t p, float* out, int dtype, gmlm_stream_t stream) {
+  GMLM_REQUIRE(b >= 0 && l >= 0 && p > 0, "meanpool_scatter_fwd: bad sizes");
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "meanpool_scatter_fwd: unsupported dtype");
+  if (b == 0) return GMLM_OK;
+  GMLM_REQUIRE(len && node_idx && out && (hs || l == 0), "meanpool_scatter_fwd: null pointer");
+  GMLM_REQUIRE(b <= 65535, "meanpool_scatter_fwd: micro-batch %ld > 65535", (long)b);
+  dim3 grid((unsigned)cdiv(p, 256), (unsigned)b);
+  if (dtype == GMLM_F32)
+    meanpool_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)hs, len, node_idx, l, p, out);
+  else
+    meanpool_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)hs, len, node_idx, l, p, out);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_meanpool_scatter_bwd(const float* dout, const int32_t* len, const int64_t* node_idx, int64_t b,
+                                         int64_t l, int64_t p, void* dhs, int dtype, gmlm_stream_t stream) {
+  GMLM_REQUIRE(b >= 0 && l >= 0 && p > 0, "meanpool_scatter_bwd: bad sizes");
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "meanpool_scatter_bwd: unsupported dtype");
+  if (b == 0 || l == 0) return GMLM_OK;
+  GMLM_REQUIRE(len && node_idx && dout && dhs, "meanpool_scatter_bwd: null pointer");
+  GMLM_REQUIRE(b <= 65535, "meanpool_scatter_bwd: micro-batch %ld > 65535", (long)b);
+  dim3 grid((unsigned)cdiv(p, 256), (unsigned)b);
+  if (dtype == GMLM_F32)
+    meanpool_bwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (float*)dhs);
+  else
+    meanpool_bwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (bf16_t*)dhs);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_softmask_blend_fwd(const float* x, const uint8_t* mask, const float* token, float beta, int64_t n,
+                                       int64_t f, void* out, int64_t out_stride, int dtype, gmlm_stream_t stream) {
+  GMLM_REQUIRE(n >= 0 && f > 0 && out_stride >= f, "softmask_blend_fwd: bad sizes");
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "softmask_blend_fwd: unsupported dtype");
+  if (n == 0) return GMLM_OK;
+  GMLM_REQUIRE(x && mask && token && out, "softmask_blend_fwd: null pointer");
+  dim3 grid = stream_grid(n, out_stride);
+  if (dtype == GMLM_F32)
+    softmask_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(x, mask, token, beta, n, f, (float*)out, out_stride);
+  else
+    softmask_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(x, mask, token, beta, n, f, (bf16_t*)out, out_stride);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_softmask_blend_bwd(const float* dout, int64_t dout_stride, const uint8_t* mask, float beta, int64_t n,
+                                       int64_t f, float* dtoken, void* workspace, size_t workspace_bytes,
+                                       gmlm_stream_t stream) {
+  GMLM_REQUIRE(n >= 0 && f > 0 && dout_stride >= f && dtoken, "softmask_blend_bwd: bad arguments");
+  GMLM_REQUIRE(n == 0 || (dout && mask), "softmask_blend_bwd: null pointer");
+  return col_reduce<1>(n, f, SoftmaskBwdFn{dout, dout_stride, mask}, dtoken, workspace, workspace_bytes, as_stream(stream),
+                       beta);
+}
+
+static int bg_check(const char* who, int64_t rows, int64_t f, int dtype, float p) {
+  GMLM_REQUIRE(rows >= 0 && f > 0, "%s: bad sizes", who);
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "%s: unsupported dtype", who);
+  GMLM_REQUIRE(f % (dtype == GMLM_F32 ? 4 : 8) == 0, "%s: width %ld must be a multiple of %d", who, (long)f, dtype == GMLM_F32 ? 4 : 8);
+  GMLM_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout_p must be in [0,1)", who);
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed,
+                                  void* y, int dtype, gmlm_stream_t stream) {
+  int rc = bg_check("bias_gelu_fwd", rows, f, dtype, dropout_p);
+  if (rc != GMLM_OK) return rc;
+  if (rows == 0) return GMLM_OK;
+  GMLM_REQUIRE(x && y && aligned16(x) && aligned16(y), "bias_gelu_fwd: null or misaligned pointer");
+  const uint32_t th = dropout_threshold(dropout_p);
+  const float ks = 1.f / (1.f - dropout_p);
+  if (dtype == GMLM_F32)
+    bias_gelu_fwd_kernel<float><<<stream_grid(rows, f / 4), 256, 0, as_stream(stream)>>>((const float*)x, bias, rows, f, th, ks, seed, (float*)y);
+  else
+    bias_gelu_fwd_kernel<bf16_t><<<stream_grid(rows, f / 8), 256, 0, as_stream(stream)>>>((const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)y);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
+                                  uint64_t seed, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
+                                  gmlm_stream_t stream) {
+  int rc = bg_check("bias_gelu_bwd", rows, f, dtype, dropout_p);
+  if (rc != GMLM_OK) return rc;
+  hipStream_t st = as_stream(stream);
+  if (rows > 0) {
+    GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
+    const uint32_t th = dropout_threshold(dropout_p);
+    const float ks = 1.f / (1.f - dropout_p);
+    if (dtype == GMLM_F32)
+      bias_gelu_bwd_kernel<float><<<stream_grid(rows, f / 4), 256, 0, st>>>((const float*)dy, (const float*)x, bias, rows, f, th, ks, seed, (float*)dx);
+    else
+      bias_gelu_bwd_kernel<bf16_t><<<stream_grid(rows, f / 8), 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)dx);
+    GMLM_LAUNCH_CHECK();
+  }
+  if (!dbias) return GMLM_OK;
+  if (dtype == GMLM_F32) return col_reduce<1>(rows, f, ColSumFn<float>{(const float*)dx, f}, dbias, workspace, workspace_bytes, st);
+  return col_reduce<1>(rows, f, ColSumFn<bf16_t>{(const bf16_t*)dx, f}, dbias, workspace, workspace_bytes, st);
+}

@@ -1,0 +1,138 @@
+"""Per-graph preprocessing for the RGCN aggregation (K1), cached because the graph is static.
+
+The reference recomputes edge types with a per-edge Python loop on every call (main.py:253-267) and
+PyG re-masks ``edge_index`` per relation on every layer call.  Here one pass builds
+  * ``edge_type``  int64 [E]              (bit-exact with the reference loop)
+  * a target-sorted, relation-segmented CSR:  segment s = dst * R_a + slot(rel)
+        rowptr int32 [N*R_a + 1], col int32 [E] (source node of each sorted edge)
+  * its transpose (source-sorted) for the backward pass:
+        t_rowptr int32 [N_src + 1], t_seg int32 [E] (forward segment of each edge), inv_cnt f32 [N*R_a]
+Only relations that actually occur get a slot (R_a <= num_relations); the empty ones contribute
+exactly zero in the reference (mean over an empty neighbourhood), so they are skipped.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import torch
+
+from ._lib import check, lib
+from .ops import _cuda, _ptr, _stream, _ws, edge_types_from_degree
+
+
+@dataclass
+class RelCSR:
+    num_nodes: int            # target rows
+    num_src: int              # rows of the source feature matrix (== num_nodes unless halo rows are appended)
+    num_edges: int
+    num_relations: int
+    active_relations: List[int]
+    edge_type: torch.Tensor   # int64 [E]
+    rowptr: torch.Tensor      # int32 [N*R_a+1]
+    col: torch.Tensor         # int32 [E]
+    perm: torch.Tensor        # int32 [E] original edge id of each sorted edge
+    inv_cnt: torch.Tensor     # f32 [N*R_a]
+    t_rowptr: torch.Tensor    # int32 [N_src+1]
+    t_seg: torch.Tensor       # int32 [E]
+
+    @property
+    def r_active(self) -> int:
+        return len(self.active_relations)
+
+
+def _segment_sort(node, rel, remap, r_active, num_segments):
+    e = node.numel()
+    dev = node.device
+    keys = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    perm = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    rowptr = torch.empty(num_segments + 1, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws = _ws(lib().gmlm_segment_sort_workspace_bytes(e), dev)
+    check(lib().gmlm_segment_sort(_ptr(node), _ptr(rel), _ptr(remap), r_active, e, num_segments, _ptr(keys), _ptr(perm),
+                                  _ptr(rowptr), _ptr(bad), _ptr(ws), ws.numel(), _stream()), "gmlm_segment_sort")
+    return keys[:e], perm[:e], rowptr, bad
+
+
+def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
+                  edge_type: Optional[torch.Tensor] = None, num_src: Optional[int] = None,
+                  src_degree_for_types: Optional[torch.Tensor] = None) -> RelCSR:
+    """edge_index int64 [2, E] with edge_index[0] = source (row of x), edge_index[1] = target in [0, num_nodes).
+
+    ``num_src`` > num_nodes allows source ids that point at appended halo rows (multi-GPU partition).
+    ``src_degree_for_types``: optional int32 global out-degree per source row, used instead of the
+    local histogram when the graph is a partition.
+    """
+    _cuda(edge_index)
+    edge_index = edge_index.to(torch.long)
+    src = edge_index[0].contiguous()
+    dst = edge_index[1].contiguous()
+    e = src.numel()
+    dev = src.device
+    num_src = int(num_src) if num_src else num_nodes
+    st = _stream()
+    if edge_type is None:
+        if src_degree_for_types is None:
+            edge_type = edge_types_from_degree(edge_index, num_src)
+        else:
+            edge_type = torch.empty(e, dtype=torch.long, device=dev)
+            deg = src_degree_for_types.to(torch.int32).contiguous()
+            check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, _ptr(edge_type), st), "gmlm_edge_bucket")
+    else:
+        edge_type = edge_type.to(device=dev, dtype=torch.long).contiguous()
+    cnt = torch.empty(num_relations, dtype=torch.int32, device=dev)
+    check(lib().gmlm_relation_histogram(_ptr(edge_type), e, num_relations, _ptr(cnt), st), "gmlm_relation_histogram")
+    cnt_h = cnt.cpu()                                   # one small D2H per graph (cached afterwards)
+    if int(cnt_h.sum()) != e:
+        raise ValueError(f"edge_type has values outside [0, {num_relations})")
+    active = [r for r in range(num_relations) if int(cnt_h[r]) > 0] or [0]
+    remap_h = torch.full((num_relations,), -1, dtype=torch.int32)
+    for slot, r in enumerate(active):
+        remap_h[r] = slot
+    remap = remap_h.to(dev)
+    r_a = len(active)
+    nseg = num_nodes * r_a
+    keys, perm, rowptr, bad = _segment_sort(dst, edge_type, remap, r_a, nseg)
+    col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    check(lib().gmlm_gather_i64_to_i32(_ptr(src), _ptr(perm), e, _ptr(col), st), "gmlm_gather_i64_to_i32")
+    inv_cnt = torch.empty(max(nseg, 1), dtype=torch.float32, device=dev)
+    check(lib().gmlm_segment_inv_count(_ptr(rowptr), nseg, _ptr(inv_cnt), st), "gmlm_segment_inv_count")
+    # transpose: sort by source node; carry the forward segment key of each edge
+    _, t_perm, t_rowptr, bad2 = _segment_sort(src, None, None, 1, num_src)
+    t_seg = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+    check(lib().gmlm_gather_i32(_ptr(keys), _ptr(t_perm), e, _ptr(t_seg), st), "gmlm_gather_i32")
+    flags = torch.cat([bad, bad2]).cpu()
+    if int(flags.abs().sum()) != 0:
+        raise ValueError("edge_index / edge_type contain ids outside the graph (targets must be < num_nodes, "
+                         "sources < num_src, relations < num_relations)")
+    return RelCSR(num_nodes, num_src, e, num_relations, active, edge_type, rowptr, col[:e], perm, inv_cnt[:nseg], t_rowptr,
+                  t_seg[:e])
+
+
+class GraphCache:
+    """Small LRU keyed by the identity of ``edge_index`` / ``edge_type`` storage (static graph)."""
+
+    def __init__(self, capacity: int = 4):
+        self.capacity = capacity
+        self._items = {}
+
+    @staticmethod
+    def _key(edge_index, edge_type, num_nodes, num_relations):
+        k = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, num_nodes, num_relations)
+        if edge_type is not None:
+            k += (edge_type.data_ptr(), edge_type._version)
+        return k
+
+    def get(self, edge_index, num_nodes, num_relations, edge_type=None) -> RelCSR:
+        key = self._key(edge_index, edge_type, num_nodes, num_relations)
+        hit = self._items.get(key)
+        if hit is not None:
+            return hit[0]
+        csr = build_rel_csr(edge_index, num_nodes, num_relations, edge_type)
+        if len(self._items) >= self.capacity:
+            self._items.pop(next(iter(self._items)))
+        self._items[key] = (csr, edge_index, edge_type)   # keep the keyed tensors alive: data_ptr stays unique
+        return csr
+
+    def clear(self):
+        self._items.clear()

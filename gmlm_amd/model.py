@@ -1,0 +1,220 @@
+"""``GraphTextLM`` — drop-in for main.py:182-372 on the gfx950 kernel path.
+
+Same constructor arguments, attribute names (load-bearing for ``setup_optimizer`` /
+``pretrain_contrastive_gnn``, main.py:379-390, 409-427), state-dict keys, ``get_graph_embeddings`` and
+``forward`` signatures.  What differs is how it is computed:
+
+* edge types + relation CSR are built once per graph on the GPU (K1) instead of a per-edge Python loop;
+* each RGCN block = K2 aggregation -> one hipBLASLt GEMM per operand -> K4 GraphNorm+GELU+dropout;
+* the PLM runs on K5/K6 (gmlm_amd.bert) from pre-tokenised ids cached on the device; pooling +
+  scatter is K8;
+* both CrossAttention modules use the streaming attention kernel K7 (no N x N score matrix);
+* fusion LayerNorm+GELU and classifier GELU are fused epilogues (K6 / bias_gelu).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch.utils.checkpoint import checkpoint
+
+from . import bert, ops
+from .graph import GraphCache, RelCSR
+from .nn import CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, compute_dtype
+
+logger = logging.getLogger(__name__)
+
+
+class TokenizedTexts:
+    """Device-resident tokenisation of all node texts (replaces per-step host tokenisation and the
+    per-node ``.item()`` of main.py:338-345).  ``input_ids`` int32 [N, Lmax], ``lens`` int32 [N]."""
+
+    def __init__(self, input_ids: torch.Tensor, lens: torch.Tensor):
+        self.input_ids = input_ids.to(torch.int32).contiguous()
+        self.lens = lens.to(torch.int32).contiguous()
+        self.lens_host = self.lens.cpu()
+
+    @classmethod
+    def from_mask(cls, input_ids: torch.Tensor, attention_mask: torch.Tensor):
+        return cls(input_ids, attention_mask.sum(-1))
+
+    def to(self, device):
+        return TokenizedTexts(self.input_ids.to(device), self.lens.to(device))
+
+
+class GraphTextLM(nn.Module):
+    def __init__(self, gnn_in_channels, hidden_channels, num_classes, num_relations=5, num_bases=30, dropout_rate=0.3,
+                 model_name='thenlper/gte-base', plm_max_length=256, *, plm_encoder=None, plm_tokenizer=None,
+                 compute_dtype: Optional[torch.dtype] = None, activation_checkpointing: bool = False,
+                 plm_gradient_checkpointing: bool = False):
+        super().__init__()
+        self.gnn_mask_token_embed = nn.Parameter(torch.zeros(1, gnn_in_channels))
+        nn.init.xavier_uniform_(self.gnn_mask_token_embed)
+        hc = hidden_channels
+        self.rgcn1 = RGCNConv(gnn_in_channels, hc, num_relations=num_relations, num_bases=num_bases)
+        self.gnorm1 = GraphNorm(hc)
+        self.dropout1 = nn.Dropout(dropout_rate)
+        self.rgcn2 = RGCNConv(hc, hc * 2, num_relations=num_relations, num_bases=num_bases)
+        self.gnorm2 = GraphNorm(hc * 2)
+        self.dropout2 = nn.Dropout(dropout_rate)
+        self.rgcn3 = RGCNConv(hc * 2, hc * 4, num_relations=num_relations, num_bases=num_bases)
+        self.gnorm3 = GraphNorm(hc * 4)
+        self.dropout3 = nn.Dropout(dropout_rate)
+        self.rgcn4 = RGCNConv(hc * 4, hc * 8, num_relations=num_relations, num_bases=num_bases)
+        self.gnorm4 = GraphNorm(hc * 8)
+        self.dropout4 = nn.Dropout(dropout_rate)
+        self.residual_proj1 = nn.Linear(gnn_in_channels, hc)
+        self.residual_proj2 = nn.Linear(hc, hc * 2)
+        self.residual_proj3 = nn.Linear(hc * 2, hc * 8)   # dead branch in the reference (main.py:317-318); kept for the state dict
+
+        if plm_encoder is None:
+            from transformers import AutoModel, AutoTokenizer
+            logger.info("Loading HuggingFace model: %s", model_name)
+            plm_encoder = AutoModel.from_pretrained(model_name, trust_remote_code=True)
+            if plm_tokenizer is None:
+                plm_tokenizer = AutoTokenizer.from_pretrained(model_name, trust_remote_code=True)
+        bert.check_supported(plm_encoder)
+        self.plm_encoder = plm_encoder
+        self.plm_tokenizer = plm_tokenizer
+        self.plm_max_length = plm_max_length
+        p = self.plm_encoder.config.hidden_size
+
+        self.multi_scale_fusion = MultiScaleFusion([hc, hc * 2, hc * 4, hc * 8], p)
+        self.graph_to_text_attn = CrossAttention(p, num_heads=8, dropout=dropout_rate)
+        self.text_to_graph_attn = CrossAttention(p, num_heads=8, dropout=dropout_rate)
+        self.fusion_network = nn.Sequential(nn.Linear(p * 2, p), nn.LayerNorm(p), nn.GELU(), nn.Dropout(dropout_rate))
+        self.classifier = nn.Sequential(nn.Linear(p, hc), nn.GELU(), nn.Dropout(dropout_rate), nn.Linear(hc, num_classes))
+
+        self.num_relations = num_relations
+        self.compute_dtype = compute_dtype
+        self.activation_checkpointing = activation_checkpointing
+        self.plm_gradient_checkpointing = plm_gradient_checkpointing
+        self._graphs = GraphCache(capacity=4)
+        self._tokens = {}
+        self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
+
+    # ------------------------------------------------------------------------------------------
+    def _cd(self) -> torch.dtype:
+        return compute_dtype(self.compute_dtype)
+
+    def graph(self, edge_index: torch.Tensor, num_nodes: int, edge_type=None) -> RelCSR:
+        if self.dist is not None:
+            return self.dist.csr
+        return self._graphs.get(edge_index, num_nodes, self.num_relations, edge_type)
+
+    def soft_mask_input(self, x, mask, beta=0.7):
+        """Fused soft masking (K9) straight into the compute dtype with 16-byte aligned rows."""
+        cd = self._cd()
+        align = 8 if cd == torch.bfloat16 else 4
+        cols = (x.shape[1] + align - 1) // align * align
+        return ops.soft_masking_gnn_input(x, mask, self.gnn_mask_token_embed, beta, cd, cols)
+
+    def _block(self, k: int, x: torch.Tensor, csr: RelCSR) -> torch.Tensor:
+        conv, norm, drop = getattr(self, f"rgcn{k}"), getattr(self, f"gnorm{k}"), getattr(self, f"dropout{k}")
+        if self.dist is not None:
+            x = self.dist.with_halo(x)                                # [n_local + n_halo, F]
+        z = conv.forward_csr(x, csr)                                  # fp32 [n, out]
+        cd = x.dtype
+        n_total = self.dist.n_total if self.dist is not None else z.size(0)
+        if n_total > 1:                                               # main.py:273 guard
+            reducer = self.dist.all_reduce_sum if self.dist is not None else None
+            return norm(z, act=True, dropout_p=drop.p, out_dtype=cd, reducer=reducer, n_total=n_total)
+        return ops.bias_gelu(z.to(cd), None, drop.p, self.training)
+
+    def get_graph_embeddings(self, x_feat, edge_index, edge_type=None):
+        edge_index = edge_index.to(torch.long)
+        csr = self.graph(edge_index, x_feat.size(0), edge_type)
+        cd = self._cd()
+        align = 8 if cd == torch.bfloat16 else 4
+        f_in = self.rgcn1.in_channels
+        if x_feat.shape[1] == f_in:
+            pad = (-f_in) % align
+            x0 = x_feat.to(cd)
+            if pad:
+                x0 = torch.nn.functional.pad(x0, (0, pad))
+        else:                                                          # already padded by soft_mask_input
+            x0 = x_feat.to(cd)
+        x0 = x0.contiguous()
+        run = (lambda k, x: checkpoint(self._block, k, x, csr, use_reentrant=False)) \
+            if (self.activation_checkpointing and self.training and torch.is_grad_enabled()) else \
+            (lambda k, x: self._block(k, x, csr))
+        e1 = run(1, x0)
+        x1 = (e1.float() + _linear(x0[:, :f_in] if x0.shape[1] != f_in else x0, self.residual_proj1.weight,
+                                   self.residual_proj1.bias).float()).to(cd)
+        e2 = run(2, x1)
+        x2 = (e2.float() + _linear(x1, self.residual_proj2.weight, self.residual_proj2.bias).float()).to(cd)
+        e3 = run(3, x2)
+        e4 = run(4, e3)
+        # main.py:317-318 computes x4 + residual_proj3(x2) and discards it: skipped (no effect on outputs or grads)
+        return self.multi_scale_fusion([e1, e2, e3, e4])
+
+    # ------------------------------------------------------------------------------------------
+    def tokenize(self, all_node_texts) -> TokenizedTexts:
+        """Tokenise every node text once on the host (same tokenizer call as main.py:342-345) and keep
+        the ids on the device; keyed by the identity of the text list."""
+        if isinstance(all_node_texts, TokenizedTexts):
+            return all_node_texts
+        key = id(all_node_texts)
+        hit = self._tokens.get(key)
+        if hit is not None and hit[1] is all_node_texts:
+            return hit[0]
+        enc = self.plm_tokenizer(list(all_node_texts), padding=True, truncation=True, max_length=self.plm_max_length,
+                                 return_tensors="pt")
+        dev = self.gnn_mask_token_embed.device
+        tt = TokenizedTexts.from_mask(enc["input_ids"].to(dev), enc["attention_mask"].to(dev))
+        self._tokens = {key: (tt, all_node_texts)}
+        return tt
+
+    def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8) -> torch.Tensor:
+        """main.py:328-358: PLM over the active nodes in micro-batches, masked mean pool, row scatter."""
+        n = node_mask.numel()
+        dev = node_mask.device
+        p = self.plm_encoder.config.hidden_size
+        plm_embeds = torch.zeros(n, p, device=dev)
+        idx = node_mask.nonzero(as_tuple=True)[0]                     # one D2H sync for the count
+        a = idx.numel()
+        if a == 0:
+            return plm_embeds
+        cd = self._cd()
+        idx_h = idx.cpu()
+        lens_h = tokens.lens_host[idx_h]
+        grad = self.plm_encoder.training or self.training
+        with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
+            for s in range(0, a, plm_batch_size):
+                bi = idx[s:s + plm_batch_size]
+                lmax = max(int(lens_h[s:s + plm_batch_size].max()), 1)   # host-side: no sync
+                ids = tokens.input_ids[bi, :lmax]
+                lens = tokens.lens[bi]
+                hs = bert.bert_encode(self.plm_encoder, ids, lens, cd, self.plm_encoder.training,
+                                      self.plm_gradient_checkpointing)
+                plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, lens, bi)
+        return plm_embeds
+
+    def forward(self, gnn_input_features, edge_index, all_node_texts, text_processing_node_mask, edge_type=None,
+                plm_batch_size=8):
+        edge_index = edge_index.to(torch.long)
+        gnn_embeds = self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)      # fp32 [N, P]
+        tokens = self.tokenize(all_node_texts)
+        plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size)       # fp32 [N, P]
+        return self.head(gnn_embeds, plm_embeds)
+
+    def head(self, gnn_embeds, plm_embeds):
+        """main.py:360-372."""
+        cd = self._cd()
+        g = gnn_embeds.unsqueeze(0)
+        t = plm_embeds.unsqueeze(0)
+        gather = self.dist.all_gather_rows if self.dist is not None else None
+        gnn_attended = self.graph_to_text_attn(g, t, gather)
+        text_attended = self.text_to_graph_attn(t, g, gather)
+        fn = self.fusion_network
+        pdim = gnn_attended.shape[-1]
+        w = fn[0].weight
+        fused = _linear(gnn_attended, w[:, :pdim]) + _linear(text_attended, w[:, pdim:])        # cat-free Linear(2P -> P)
+        fused = ops.bias_res_layernorm(fused, fn[0].bias, None, fn[1].weight, fn[1].bias, fn[1].eps, True, fn[3].p,
+                                       self.training)
+        fused = fused.squeeze(0)
+        c = self.classifier
+        hcls = ops.bias_gelu(_linear(fused, c[0].weight), c[0].bias, c[2].p, self.training)
+        return _linear(hcls, c[3].weight, c[3].bias).float()

@@ -1,0 +1,188 @@
+"""nn.Module surface of the operators the reference reaches through PyG / its own small modules.
+
+* ``RGCNConv`` / ``GraphNorm`` / ``degree`` keep the PyG call signatures used at main.py:189-203,
+  256, 272-309 (parameter names ``weight, comp, root, bias`` / ``weight, bias, mean_scale``) so a
+  reference state dict loads unchanged.
+* ``CrossAttention`` / ``MultiScaleFusion`` keep main.py:139-180's names and shapes.
+All arithmetic that is not a plain dense GEMM runs in libgmlm_hip.so (gmlm_amd.ops); dense
+projections go to hipBLASLt through ``torch.mm`` / ``F.linear``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import GraphCache, RelCSR
+
+_GRAPHS = GraphCache(capacity=8)
+
+
+def compute_dtype(module_dtype: Optional[torch.dtype] = None) -> torch.dtype:
+    """fp32 unless the caller runs under ``torch.amp.autocast('cuda')`` (main.py:348,446,543) or set an
+    explicit dtype; autocast (fp16 or bf16) maps to bf16, the reduced precision these kernels have."""
+    if module_dtype is not None:
+        return module_dtype
+    if torch.is_autocast_enabled("cuda"):
+        return torch.bfloat16
+    return torch.float32
+
+
+def _glorot(t: torch.Tensor) -> None:
+    a = math.sqrt(6.0 / (t.size(-2) + t.size(-1)))
+    with torch.no_grad():
+        t.uniform_(-a, a)
+
+
+def _linear(x, weight, bias=None):
+    """x @ weight^T (+ bias) in x's dtype with autocast off (explicit precision policy)."""
+    with torch.autocast("cuda", enabled=False):
+        w = weight.to(x.dtype)
+        b = None if bias is None else bias.to(x.dtype)
+        return F.linear(x, w, b)
+
+
+class RGCNConv(nn.Module):
+    """PyG ``RGCNConv(in, out, num_relations, num_bases)`` with aggr='mean', root weight and bias."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_relations: int, num_bases: Optional[int] = None, **kw):
+        super().__init__()
+        if kw:
+            raise TypeError(f"unsupported RGCNConv options: {sorted(kw)}")
+        if num_bases is None:
+            raise NotImplementedError("only the basis-decomposed form used by the reference (num_bases=30) is implemented")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.num_relations, self.num_bases = num_relations, num_bases
+        self.weight = nn.Parameter(torch.empty(num_bases, in_channels, out_channels))
+        self.comp = nn.Parameter(torch.empty(num_relations, num_bases))
+        self.root = nn.Parameter(torch.empty(in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        _glorot(self.weight), _glorot(self.comp), _glorot(self.root)
+        nn.init.zeros_(self.bias)
+
+    def relation_weights(self, csr: RelCSR, dtype, in_pad: int = 0) -> torch.Tensor:
+        """[R_a * (in + pad), out]: W_r = sum_b comp[r, b] weight[b] for the relations that occur."""
+        comp = self.comp[csr.active_relations]                               # [R_a, B]
+        w = (comp @ self.weight.view(self.num_bases, -1)).view(len(csr.active_relations), self.in_channels,
+                                                               self.out_channels)
+        if in_pad:
+            w = F.pad(w, (0, 0, 0, in_pad))
+        return w.reshape(-1, self.out_channels).to(dtype)
+
+    def forward_csr(self, x: torch.Tensor, csr: RelCSR) -> torch.Tensor:
+        """x: [n_src, in (+pad)] in the compute dtype -> fp32 [n, out]."""
+        in_pad = x.shape[1] - self.in_channels
+        n = csr.num_nodes
+        h = ops.RGCNAggregate.apply(x, csr)                                   # [n, R_a*(in+pad)]
+        with torch.autocast("cuda", enabled=False):
+            w = self.relation_weights(csr, x.dtype, in_pad)
+            root = self.root if not in_pad else F.pad(self.root, (0, 0, 0, in_pad))
+            out = torch.mm(h, w).float()
+            out = out + torch.mm(x[:n], root.to(x.dtype)).float()
+            return out + self.bias.float()
+
+    def forward(self, x, edge_index, edge_type):
+        csr = _GRAPHS.get(edge_index, x.size(0), self.num_relations, edge_type)
+        cd = compute_dtype()
+        return self.forward_csr(x.to(cd).contiguous(), csr)
+
+
+class GraphNorm(nn.Module):
+    """PyG ``GraphNorm(in_channels, eps=1e-5)`` for a single graph (batch=None)."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = nn.Parameter(torch.ones(in_channels))
+
+    def forward(self, x, batch=None, *, act: bool = False, dropout_p: float = 0.0, out_dtype=None, reducer=None,
+                n_total=None):
+        if batch is not None:
+            raise NotImplementedError("GraphNorm over several graphs (batch vector) is outside the hot path")
+        p = float(dropout_p) if self.training else 0.0
+        return ops.GraphNormAct.apply(x, self.weight, self.bias, self.mean_scale, self.eps, act, p,
+                                      ops.draw_seed() if p > 0 else 0, out_dtype or torch.float32, reducer, n_total)
+
+
+def degree(index, num_nodes=None, dtype=None):
+    return ops.degree(index, num_nodes, dtype or torch.float32)
+
+
+class CrossAttention(nn.Module):
+    """main.py:139-165.  The dense [1,8,N,N] softmax is replaced by the streaming kernel (K7)."""
+
+    def __init__(self, dim, num_heads=8, dropout=0.1):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.q_proj = nn.Linear(dim, dim)
+        self.k_proj = nn.Linear(dim, dim)
+        self.v_proj = nn.Linear(dim, dim)
+        self.out_proj = nn.Linear(dim, dim)
+        self.dropout = nn.Dropout(dropout)
+        self.compute_dtype: Optional[torch.dtype] = None
+
+    def forward(self, x, y, kv_gather=None):
+        """x: [B, N, C] queries, y: [B, M, C] keys/values (the reference calls it with B == 1).
+
+        ``kv_gather``: optional callable mapping the local [B, M, 2C] K|V projection to the global one
+        (all-gather over the node partition)."""
+        cd = compute_dtype(self.compute_dtype)
+        b, n, c = x.shape
+        xq, yk = x.to(cd), y.to(cd)
+        q = _linear(xq, self.q_proj.weight, self.q_proj.bias)
+        wkv = torch.cat([self.k_proj.weight, self.v_proj.weight], 0)
+        bkv = torch.cat([self.k_proj.bias, self.v_proj.bias], 0)
+        kv = _linear(yk, wkv, bkv)                                    # [B, M, 2C] fused K|V
+        if kv_gather is not None:
+            kv = kv_gather(kv)
+        o = attention_any_dim(q, kv[..., :c], kv[..., c:], None, self.num_heads, self.scale, self.dropout.p, self.training)
+        return _linear(o, self.out_proj.weight, self.out_proj.bias)
+
+
+def attention_any_dim(q, k, v, kv_len, num_heads, scale, dropout_p, training):
+    """K5/K7 with head dims the MFMA tiling does not cover natively zero-padded to 64 / 96 (exact:
+    zero columns change neither the scores nor the real output columns)."""
+    b, lq, hd = q.shape
+    d = hd // num_heads
+    if d in (64, 96):
+        return ops.attention(q, k, v, kv_len, num_heads, scale, dropout_p, training)
+    if d > 96:
+        raise NotImplementedError(f"attention head dim {d} > 96 is not supported by the gfx950 kernels")
+    dp = 64 if d < 64 else 96
+
+    def pad(t):
+        return F.pad(t.reshape(t.shape[0], t.shape[1], num_heads, d), (0, dp - d)).reshape(t.shape[0], t.shape[1], num_heads * dp)
+
+    o = ops.attention(pad(q), pad(k), pad(v), kv_len, num_heads, scale, dropout_p, training)
+    return o.reshape(b, lq, num_heads, dp)[..., :d].reshape(b, lq, hd)
+
+
+class MultiScaleFusion(nn.Module):
+    """main.py:167-180: LayerNorm(sum_k softmax(w)_k * Linear_k(emb_k))."""
+
+    def __init__(self, hidden_dims, output_dim):
+        super().__init__()
+        self.scale_weights = nn.Parameter(torch.ones(len(hidden_dims)) / len(hidden_dims))
+        self.projections = nn.ModuleList([nn.Linear(dim, output_dim) for dim in hidden_dims])
+        self.layer_norm = nn.LayerNorm(output_dim)
+        self.compute_dtype: Optional[torch.dtype] = None
+
+    def forward(self, embeddings_list):
+        cd = compute_dtype(self.compute_dtype)
+        weights = F.softmax(self.scale_weights.float(), dim=0)
+        acc = None
+        for w, proj, emb in zip(weights, self.projections, embeddings_list):
+            t = _linear(emb.to(cd), proj.weight, proj.bias).float() * w
+            acc = t if acc is None else acc + t
+        ln = self.layer_norm
+        return ops.bias_res_layernorm(acc, None, None, ln.weight, ln.bias, ln.eps)

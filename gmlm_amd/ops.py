@@ -1,0 +1,422 @@
+"""Autograd operators over libgmlm_hip.so.  Every op is the HIP path; there is no eager fallback.
+
+Tensors are PyTorch-owned device memory handed to the C ABI as raw pointers together with
+``torch.cuda.current_stream()``; the library never allocates, frees or synchronises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, check, lib
+
+
+# ---------------------------------------------------------------------------------------------
+# small helpers
+# ---------------------------------------------------------------------------------------------
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"gmlm_amd kernels take float32 or bfloat16 tensors, got {t.dtype}")
+
+
+def _cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.GmlmHipError("gmlm_amd ops run on the GPU only (tensor on %s); there is no CPU path" % t.device)
+    dev = next(t for t in ts if t is not None).device
+    _lib.require_gfx950(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().float().contiguous()
+
+
+def draw_seed() -> int:
+    """Dropout seed from torch's CPU generator: replayed by torch.utils.checkpoint (RNG state is
+    preserved there), costs no device sync."""
+    return int(torch.randint(0, 2 ** 62, (1,), device="cpu").item())
+
+
+# ---------------------------------------------------------------------------------------------
+# K1: degree / edge types (integer)
+# ---------------------------------------------------------------------------------------------
+def degree(index: torch.Tensor, num_nodes: Optional[int] = None, dtype=torch.float32) -> torch.Tensor:
+    """Drop-in for ``torch_geometric.utils.degree`` (main.py:65, 256): float32 occurrence counts."""
+    _cuda(index)
+    index = index.to(torch.long).contiguous()
+    if num_nodes is None:
+        num_nodes = int(index.max().item()) + 1 if index.numel() else 0
+    if dtype == torch.float32:
+        out = torch.empty(num_nodes, dtype=torch.float32, device=index.device)
+        check(lib().gmlm_degree_f32(_ptr(index), index.numel(), num_nodes, _ptr(out), _stream()), "gmlm_degree_f32")
+        return out
+    out = torch.empty(num_nodes, dtype=torch.int32, device=index.device)
+    check(lib().gmlm_degree_i32(_ptr(index), index.numel(), num_nodes, _ptr(out), _stream()), "gmlm_degree_i32")
+    return out.to(dtype)
+
+
+def edge_types_from_degree(edge_index: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """main.py:253-267 as two kernels (degree histogram + bucketing); int64 [E], bit-exact."""
+    _cuda(edge_index)
+    src = edge_index[0].to(torch.long).contiguous()
+    e = src.numel()
+    deg = torch.empty(num_nodes, dtype=torch.int32, device=src.device)
+    check(lib().gmlm_degree_i32(_ptr(src), e, num_nodes, _ptr(deg), _stream()), "gmlm_degree_i32")
+    et = torch.empty(e, dtype=torch.long, device=src.device)
+    check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, _ptr(et), _stream()), "gmlm_edge_bucket")
+    return et
+
+
+# ---------------------------------------------------------------------------------------------
+# K2/K3: relation-segmented mean aggregation
+# ---------------------------------------------------------------------------------------------
+def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out):
+    check(lib().gmlm_rgcn_mean_spmm(_ptr(src), src.shape[0], src.stride(0), _ptr(rowptr), _ptr(idx), _ptr(edge_w),
+                                    1 if mean else 0, num_segments, f, _ptr(out), f, _dt(src), _stream()),
+          "gmlm_rgcn_mean_spmm")
+
+
+class RGCNAggregate(torch.autograd.Function):
+    """H[i, r*F:(r+1)*F] = mean_{j->i, type r} x[j]  (K2); backward = same kernel on the transposed CSR (K3)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, csr) -> torch.Tensor:
+        _cuda(x)
+        x = x.contiguous()
+        n, f = x.shape
+        if n != csr.num_nodes:
+            raise ValueError(f"x has {n} rows but the graph has {csr.num_nodes} target nodes")
+        out = torch.empty(n, csr.r_active * f, dtype=x.dtype, device=x.device)
+        _spmm(x, csr.rowptr, csr.col, None, True, n * csr.r_active, f, out)
+        ctx.csr, ctx.n_src = csr, x.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, gh: torch.Tensor):
+        csr = ctx.csr
+        gh = gh.contiguous()
+        n, rf = gh.shape
+        f = rf // csr.r_active
+        gx = torch.empty(csr.num_src, f, dtype=gh.dtype, device=gh.device)
+        _spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, csr.num_src, f, gx)
+        return gx, None
+
+
+# ---------------------------------------------------------------------------------------------
+# K4: GraphNorm + GELU + dropout
+# ---------------------------------------------------------------------------------------------
+class GraphNormAct(torch.autograd.Function):
+    """y = dropout(act(GraphNorm(z))).  z fp32 [n, f]; y in `out_dtype`.
+
+    ``reducer``: optional callable(tensor) summing a small fp32 tensor over all ranks in place (the
+    1-D node partition makes GraphNorm's column statistics global: SURVEY.md §8e); ``n_total`` is the
+    global row count.
+    """
+
+    @staticmethod
+    def forward(ctx, z, weight, bias, mean_scale, eps, act, p, seed, out_dtype, reducer, n_total):
+        _cuda(z)
+        z = z.float().contiguous()
+        n, f = z.shape
+        n_total = int(n_total) if n_total else n
+        dev = z.device
+        w, b, ms = _f32c(weight), _f32c(bias), _f32c(mean_scale)
+        st = _stream()
+        stats = torch.empty(2, f, dtype=torch.float32, device=dev)
+        shift = None
+        if reducer is None and n > 0:
+            shift = z[0].contiguous()          # shifted sums: no cancellation in E[o^2]
+        ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), dev)
+        check(lib().gmlm_colstats(_ptr(z), _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(), st),
+              "gmlm_colstats")
+        if reducer is not None:
+            # exact two-pass in the distributed case: all-reduce sum(x) -> mean, then sum((x - mean*ms)^2)
+            reducer(stats)
+            mu = stats[0] / n_total
+            shift = (mu * ms).contiguous()
+            check(lib().gmlm_colstats(_ptr(z), _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(), st),
+                  "gmlm_colstats")
+            reducer(stats)
+            mean = mu.contiguous()
+            rstd = torch.rsqrt(stats[1] / n_total + eps).contiguous()
+        else:
+            mean = torch.empty(f, dtype=torch.float32, device=dev)
+            rstd = torch.empty(f, dtype=torch.float32, device=dev)
+            check(lib().gmlm_graphnorm_finalize(_ptr(stats[0]), _ptr(stats[1]), _ptr(shift), _ptr(ms), n_total, f, eps,
+                                                _ptr(mean), _ptr(rstd), st), "gmlm_graphnorm_finalize")
+        y = torch.empty(n, f, dtype=out_dtype, device=dev)
+        check(lib().gmlm_graphnorm_apply(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms), n, f, int(act),
+                                         float(p), seed, _ptr(y), _dt(y), st), "gmlm_graphnorm_apply")
+        ctx.save_for_backward(z, mean, rstd, w, b, ms)
+        ctx.cfg = (int(act), float(p), seed, reducer, n_total)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        z, mean, rstd, w, b, ms = ctx.saved_tensors
+        act, p, seed, reducer, n_total = ctx.cfg
+        gy = gy.contiguous()
+        n, f = z.shape
+        dev = z.device
+        st = _stream()
+        gs = torch.empty(2, f, dtype=torch.float32, device=dev)
+        ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), dev)
+        check(lib().gmlm_graphnorm_bwd_stats(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms),
+                                             n, f, act, p, seed, _ptr(gs), _ptr(ws), ws.numel(), st),
+              "gmlm_graphnorm_bwd_stats")
+        gs_local = gs
+        if reducer is not None:
+            gs_local = gs.clone()
+            reducer(gs)
+        dz = torch.empty(n, f, dtype=torch.float32, device=dev)
+        if reducer is None:
+            dw = torch.empty(f, dtype=torch.float32, device=dev)
+            db = torch.empty_like(dw)
+            dms = torch.empty_like(dw)
+            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
+                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), _ptr(dw),
+                                                 _ptr(db), _ptr(dms), st), "gmlm_graphnorm_bwd_apply")
+        else:
+            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
+                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), None, None,
+                                                 None, st), "gmlm_graphnorm_bwd_apply")
+            # parameter grads: LOCAL contributions only (the gradient all-reduce sums them over ranks)
+            dw, db = gs_local[1].clone(), gs_local[0].clone()
+            m2 = gs[1] / n_total
+            mean_oh = mean * (1.0 - ms) * rstd
+            mean_do = w * rstd * (gs[0] / n_total - m2 * mean_oh)          # global mean_j do_j
+            # sum over LOCAL rows of do_j = w*rstd*(sum_local gz - m2 * sum_local ohat)
+            sum_oh_local = (z.sum(0) - n * mean * ms) * rstd
+            dms = -mean * (w * rstd * (gs_local[0] - m2 * sum_oh_local))
+            del mean_do
+        return dz, dw, db, dms, None, None, None, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# K6: bias + dropout + residual + LayerNorm (+GELU)
+# ---------------------------------------------------------------------------------------------
+class BiasResLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, residual, gamma, beta, eps, act, p, seed):
+        _cuda(x)
+        shape = x.shape
+        f = shape[-1]
+        x2 = x.contiguous().view(-1, f)
+        rows = x2.shape[0]
+        res2 = None if residual is None else residual.to(x.dtype).contiguous().view(-1, f)
+        bf = None if bias is None else _f32c(bias)
+        g, b = _f32c(gamma), _f32c(beta)
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        check(lib().gmlm_bias_res_layernorm_fwd(_ptr(x2), _ptr(bf), _ptr(res2), _ptr(g), _ptr(b), rows, f, float(eps),
+                                                int(act), float(p), seed, _ptr(y), _ptr(mean), _ptr(rstd), _dt(x2), _stream()),
+              "gmlm_bias_res_layernorm_fwd")
+        ctx.save_for_backward(x2, res2, bf, g, b, mean, rstd)
+        ctx.cfg = (int(act), float(p), seed, shape, bias is not None, residual is not None)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, res2, bf, g, b, mean, rstd = ctx.saved_tensors
+        act, p, seed, shape, has_bias, has_res = ctx.cfg
+        rows, f = x2.shape
+        gy2 = gy.contiguous().view(rows, f).to(x2.dtype)
+        dx = torch.empty_like(x2)
+        dres = torch.empty_like(x2) if has_res else None
+        dg = torch.empty(f, dtype=torch.float32, device=x2.device)
+        dbeta = torch.empty_like(dg)
+        dbias = torch.empty_like(dg) if has_bias else None
+        ws = _ws(lib().gmlm_layernorm_bwd_workspace_bytes(rows, f), x2.device)
+        check(lib().gmlm_bias_res_layernorm_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), _ptr(res2), _ptr(g), _ptr(b), _ptr(mean),
+                                                _ptr(rstd), rows, f, act, p, seed, _ptr(dx), _ptr(dres), _ptr(dg),
+                                                _ptr(dbeta), _ptr(dbias), _dt(x2), _ptr(ws), ws.numel(), _stream()),
+              "gmlm_bias_res_layernorm_bwd")
+        return (dx.view(shape), dbias, None if dres is None else dres.view(shape), dg, dbeta, None, None, None, None)
+
+
+def bias_res_layernorm(x, bias, residual, gamma, beta, eps=1e-5, act=False, p=0.0, training=False):
+    p = float(p) if training else 0.0
+    return BiasResLayerNorm.apply(x, bias, residual, gamma, beta, eps, act, p, draw_seed() if p > 0 else 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# K5/K7: attention core
+# ---------------------------------------------------------------------------------------------
+def _rows_view(t: torch.Tensor, h: int, d: int):
+    """[b, l, h*d-wide slice] view -> (tensor, row stride in elements); last dim must be contiguous."""
+    if t.stride(-1) != 1 or t.shape[-1] != h * d:
+        raise ValueError("attention operands must be [b, l, h*d] with a contiguous last dim")
+    if t.stride(0) != t.shape[1] * t.stride(1) and t.shape[0] > 1:
+        raise ValueError("attention operands must have batch stride = l * row stride")
+    return t.stride(1)
+
+
+class Attention(torch.autograd.Function):
+    """out[b, lq, h*d] = softmax(q k^T * scale + key-padding mask) v with streaming softmax.
+
+    q: [b, lq, h*d], k/v: [b, lk, h*d] (may be strided slices of a fused QKV buffer);
+    kv_len: int32 [b] or None.
+    """
+
+    @staticmethod
+    def forward(ctx, q, k, v, kv_len, h, scale, p, seed):
+        _cuda(q, k, v)
+        b, lq, hd = q.shape
+        lk = k.shape[1]
+        d = hd // h
+        qs, ks, vs = _rows_view(q, h, d), _rows_view(k, h, d), _rows_view(v, h, d)
+        out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
+        lse = torch.empty(b, h, lq, dtype=torch.float32, device=q.device)
+        check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
+                                       float(p), seed, _ptr(out), _ptr(lse), _dt(q), _stream()), "gmlm_attention_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, kv_len)
+        ctx.cfg = (h, float(scale), float(p), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        q, k, v, out, lse, kv_len = ctx.saved_tensors
+        h, scale, p, seed = ctx.cfg
+        b, lq, hd = q.shape
+        lk = k.shape[1]
+        d = hd // h
+        gout = gout.contiguous().to(q.dtype)
+        # one fused [.., 3*h*d] gradient buffer when q/k/v came from a fused QKV GEMM, else three
+        dq = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
+        dk = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
+        dv = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
+        ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, h, lq, lk, d), q.device)
+        check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h, lq,
+                                       lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, _ptr(dq), _ptr(dk),
+                                       _ptr(dv), hd, hd, hd, _dt(q), _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
+    p = float(dropout_p) if training else 0.0
+    return Attention.apply(q, k, v, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# K8: masked mean pool + row scatter
+# ---------------------------------------------------------------------------------------------
+class MeanPoolScatter(torch.autograd.Function):
+    """plm_embeds[node_idx[b]] = sum_t hs[b,t]*[t<len[b]] / max(len[b],1e-9)  (main.py:351-358), in place."""
+
+    @staticmethod
+    def forward(ctx, plm_embeds, hs, lens, node_idx):
+        _cuda(hs, plm_embeds)
+        hs = hs.contiguous()
+        b, l, p = hs.shape
+        check(lib().gmlm_meanpool_scatter_fwd(_ptr(hs), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(plm_embeds), _dt(hs),
+                                              _stream()), "gmlm_meanpool_scatter_fwd")
+        ctx.mark_dirty(plm_embeds)
+        ctx.save_for_backward(lens, node_idx)
+        ctx.cfg = (b, l, p, hs.dtype)
+        return plm_embeds
+
+    @staticmethod
+    def backward(ctx, g):
+        lens, node_idx = ctx.saved_tensors
+        b, l, p, dtype = ctx.cfg
+        g = g.contiguous().float()
+        dhs = torch.empty(b, l, p, dtype=dtype, device=g.device)
+        check(lib().gmlm_meanpool_scatter_bwd(_ptr(g), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(dhs), _dt(dhs), _stream()),
+              "gmlm_meanpool_scatter_bwd")
+        # rows written by this micro-batch were overwritten: no gradient flows to their previous value;
+        # the previous value is the zero-initialised buffer (a constant), so passing g through is harmless.
+        return g, dhs, None, None
+
+
+# ---------------------------------------------------------------------------------------------
+# K9: soft-mask blend
+# ---------------------------------------------------------------------------------------------
+class SoftMask(torch.autograd.Function):
+    """x~[i] = mask[i] ? (1-beta) x[i] + beta*token : x[i]  (main.py:92-99); output dtype / column
+    padding (zeros) chosen by the caller so the first RGCN layer gets 16-byte aligned rows."""
+
+    @staticmethod
+    def forward(ctx, x, mask, token, beta, out_dtype, out_cols):
+        _cuda(x)
+        x = x.float().contiguous()
+        n, f = x.shape
+        out_cols = int(out_cols) if out_cols else f
+        m8 = mask.to(torch.uint8).contiguous()
+        tok = _f32c(token).view(-1)
+        out = torch.empty(n, out_cols, dtype=out_dtype, device=x.device)
+        check(lib().gmlm_softmask_blend_fwd(_ptr(x), _ptr(m8), _ptr(tok), float(beta), n, f, _ptr(out), out_cols, _dt(out),
+                                            _stream()), "gmlm_softmask_blend_fwd")
+        ctx.save_for_backward(m8)
+        ctx.cfg = (float(beta), n, f, token.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (m8,) = ctx.saved_tensors
+        beta, n, f, tshape = ctx.cfg
+        g = g.float().contiguous()
+        dtok = torch.empty(f, dtype=torch.float32, device=g.device)
+        ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), g.device)
+        check(lib().gmlm_softmask_blend_bwd(_ptr(g), g.stride(0), _ptr(m8), beta, n, f, _ptr(dtok), _ptr(ws), ws.numel(),
+                                            _stream()), "gmlm_softmask_blend_bwd")
+        return None, None, dtok.view(tshape), None, None, None
+
+
+def soft_masking_gnn_input(x, gnn_perturb_mask, mask_token_embed, beta=0.7, out_dtype=torch.float32, out_cols=None):
+    """Drop-in for main.py:92-99 (same name / argument order); gradient flows to ``mask_token_embed``."""
+    return SoftMask.apply(x, gnn_perturb_mask.to(x.device), mask_token_embed.to(x.device), beta, out_dtype, out_cols)
+
+
+# ---------------------------------------------------------------------------------------------
+# bias + GELU (+dropout)
+# ---------------------------------------------------------------------------------------------
+class BiasGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, p, seed):
+        _cuda(x)
+        shape = x.shape
+        f = shape[-1]
+        x2 = x.contiguous().view(-1, f)
+        bf = None if bias is None else _f32c(bias)
+        y = torch.empty_like(x2)
+        check(lib().gmlm_bias_gelu_fwd(_ptr(x2), _ptr(bf), x2.shape[0], f, float(p), seed, _ptr(y), _dt(x2), _stream()),
+              "gmlm_bias_gelu_fwd")
+        ctx.save_for_backward(x2, bf)
+        ctx.cfg = (float(p), seed, shape, bias is not None)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, bf = ctx.saved_tensors
+        p, seed, shape, has_bias = ctx.cfg
+        rows, f = x2.shape
+        gy2 = gy.contiguous().view(rows, f).to(x2.dtype)
+        dx = torch.empty_like(x2)
+        dbias = torch.empty(f, dtype=torch.float32, device=x2.device) if has_bias else None
+        ws = _ws(lib().gmlm_colstats_workspace_bytes(rows, f), x2.device)
+        check(lib().gmlm_bias_gelu_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), rows, f, p, seed, _ptr(dx), _ptr(dbias), _dt(x2),
+                                       _ptr(ws), ws.numel(), _stream()), "gmlm_bias_gelu_bwd")
+        return dx.view(shape), dbias, None, None
+
+
+def bias_gelu(x, bias, p=0.0, training=False):
+    p = float(p) if training else 0.0
+    return BiasGelu.apply(x, bias, p, draw_seed() if p > 0 else 0)

@@ -1,0 +1,379 @@
+"""GPU parity tests: every kernel of libgmlm_hip.so, called through the C ABI (via gmlm_amd.ops),
+against the CPU oracle / plain fp32 torch on the same seeded inputs.  Index work is bit-exact;
+floating point tolerances are written next to each check."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gmlm_oracle as O
+from helpers import load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import gmlm_amd
+    gmlm_amd.lib()
+    from gmlm_amd._lib import device_info
+    cu, wave, arch = device_info(0)
+    assert wave == 64 and arch.startswith("gfx950"), (cu, wave, arch)
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------- K1
+def test_edge_types_and_degree_golden(dev):
+    import gmlm_amd
+    g = load_golden("g3_int")
+    for ci in range(int(g["num_cases"])):
+        n = int(g[f"c{ci}_n"])
+        ei = t(g[f"c{ci}_edge_index"]).to(dev)
+        deg = gmlm_amd.degree(ei[0], n)
+        assert deg.dtype == torch.float32 and np.array_equal(deg.cpu().numpy(), g[f"c{ci}_degree"])
+        et = gmlm_amd.edge_types_from_degree(ei, n)
+        assert et.dtype == torch.long and np.array_equal(et.cpu().numpy(), g[f"c{ci}_edge_type"])
+
+
+@pytest.mark.parametrize("n,e,r", [(1, 0, 5), (7, 3, 5), (100, 1000, 5), (5201, 217073, 5), (300, 5000, 3)])
+def test_relation_csr_bit_exact(dev, n, e, r):
+    import gmlm_amd
+    g = torch.Generator().manual_seed(n + e)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    et = torch.randint(0, r, (e,), generator=g) if r == 3 else None
+    csr = gmlm_amd.build_rel_csr(ei.to(dev), n, r, None if et is None else et.to(dev))
+    et_ref = et if et is not None else O.edge_types_from_degree(ei, n)
+    assert np.array_equal(csr.edge_type.cpu().numpy(), et_ref.numpy())
+    active = sorted(set(et_ref.tolist())) or [0]
+    assert csr.active_relations == active
+    remap = {rr: s for s, rr in enumerate(active)}
+    et_slot = torch.tensor([remap[int(v)] for v in et_ref.tolist()], dtype=torch.long)
+    rowptr, col, eid = O.relation_csr(ei, et_slot, n, len(active))
+    assert np.array_equal(csr.rowptr.cpu().numpy(), rowptr)
+    assert np.array_equal(csr.col.cpu().numpy(), col)
+    assert np.array_equal(csr.perm.cpu().numpy(), eid)
+    # transpose: sorted by source, stable; t_seg = forward segment of each edge
+    order = np.argsort(ei[0].numpy(), kind="stable")
+    key = (ei[1] * len(active) + et_slot).numpy()
+    assert np.array_equal(csr.t_seg.cpu().numpy(), key[order].astype(np.int32))
+    assert np.array_equal(csr.t_rowptr.cpu().numpy(), np.concatenate([[0], np.cumsum(np.bincount(ei[0].numpy(), minlength=n))]).astype(np.int32))
+
+
+def test_csr_rejects_bad_ids(dev):
+    import gmlm_amd
+    ei = torch.tensor([[0, 5], [1, 0]], device=dev)
+    with pytest.raises(ValueError):
+        gmlm_amd.build_rel_csr(ei, 3, 5)
+    with pytest.raises(ValueError):
+        gmlm_amd.build_rel_csr(torch.tensor([[0, 1], [1, 0]], device=dev), 3, 5, torch.tensor([0, 7], device=dev))
+
+
+# ------------------------------------------------------------------------------------------- K2/K3
+@pytest.mark.parametrize("n,e,f", [(64, 256, 32), (183, 298, 1703), (500, 6000, 768), (500, 6000, 96), (300, 3000, 2089),
+                                   (40, 0, 16), (2000, 40000, 1536), (128, 4000, 3072)])
+def test_spmm_forward_backward_fp32(dev, n, e, f):
+    from gmlm_amd import build_rel_csr
+    from gmlm_amd.ops import RGCNAggregate
+    g = torch.Generator().manual_seed(f + n)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    x = torch.randn(n, f, generator=g)
+    et = O.edge_types_from_degree(ei, n)
+    csr = build_rel_csr(ei.to(dev), n, 5)
+    xg = x.to(dev).requires_grad_(True)
+    h = RGCNAggregate.apply(xg, csr)
+    xr = x.clone().requires_grad_(True)
+    href = O.rgcn_mean_aggregate(xr, ei, et, 5)[csr.active_relations]           # [R_a, n, f]
+    href2 = href.permute(1, 0, 2).reshape(n, -1)
+    # fp32 sums of <= a few hundred terms in a different order: 1e-5 relative to the row scale
+    np.testing.assert_allclose(h.detach().cpu().numpy(), href2.detach().numpy(), rtol=1e-5, atol=1e-5)
+    go = torch.randn(h.shape, generator=g)
+    h.backward(go.to(dev))
+    href2.backward(go)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=2e-5)
+
+
+def test_spmm_bf16(dev):
+    from gmlm_amd import build_rel_csr
+    from gmlm_amd.ops import RGCNAggregate
+    n, e, f = 700, 9000, 768
+    g = torch.Generator().manual_seed(5)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    x = torch.randn(n, f, generator=g).bfloat16()
+    csr = build_rel_csr(ei.to(dev), n, 5)
+    h = RGCNAggregate.apply(x.to(dev), csr)
+    et = O.edge_types_from_degree(ei, n)
+    href = O.rgcn_mean_aggregate(x.float(), ei, et, 5)[csr.active_relations].permute(1, 0, 2).reshape(n, -1)
+    # inputs identical bf16 values, fp32 accumulation, one bf16 rounding at the end: <= 2^-8 relative
+    np.testing.assert_allclose(h.float().cpu().numpy(), href.numpy(), rtol=8e-3, atol=1e-3)
+
+
+def test_spmm_linearity_and_determinism_full_size(dev):
+    """Squirrel-size (BASELINE headline): A(ax + by) = aA(x) + bA(y); two launches bit-identical."""
+    from gmlm_amd import build_rel_csr
+    from gmlm_amd.ops import RGCNAggregate
+    n, e, f = 5201, 217073, 768
+    g = torch.Generator().manual_seed(1002)
+    ei = torch.randint(0, n, (2, e), generator=g).to(dev)
+    x, y = torch.randn(n, f, generator=g).to(dev), torch.randn(n, f, generator=g).to(dev)
+    csr = build_rel_csr(ei, n, 5)
+    hx, hy = RGCNAggregate.apply(x, csr), RGCNAggregate.apply(y, csr)
+    hxy = RGCNAggregate.apply(2.0 * x - 0.5 * y, csr)
+    assert torch.allclose(hxy, 2.0 * hx - 0.5 * hy, rtol=1e-4, atol=1e-4)
+    assert torch.equal(hx, RGCNAggregate.apply(x, csr))
+    # mean of a constant field is that constant wherever a node has neighbours of that relation
+    ones = RGCNAggregate.apply(torch.ones(n, 8, device=dev), csr).view(n, csr.r_active, 8)
+    cnt = (csr.rowptr[1:] - csr.rowptr[:-1]).view(n, csr.r_active)
+    assert torch.equal(ones[..., 0], (cnt > 0).float())
+
+
+# ------------------------------------------------------------------------------------------- K4
+@pytest.mark.parametrize("n,f,act", [(2, 16, True), (183, 64, True), (1000, 768, False), (777, 100, True)])
+def test_graphnorm_fwd_bwd(dev, n, f, act):
+    from gmlm_amd.ops import GraphNormAct
+    g = torch.Generator().manual_seed(n * f)
+    z = torch.randn(n, f, generator=g) * 2 + 0.7
+    w, b, ms = (1 + 0.1 * torch.randn(f, generator=g)), 0.1 * torch.randn(f, generator=g), 1 + 0.1 * torch.randn(f, generator=g)
+    go = torch.randn(n, f, generator=g)
+    ref_in = [v.clone().requires_grad_(True) for v in (z, w, b, ms)]
+    yr = O.graph_norm(*ref_in)
+    if act:
+        yr = F.gelu(yr)
+    yr.backward(go)
+    dev_in = [v.to(dev).requires_grad_(True) for v in (z, w, b, ms)]
+    y = GraphNormAct.apply(dev_in[0], dev_in[1], dev_in[2], dev_in[3], 1e-5, act, 0.0, 0, torch.float32, None, None)
+    y.backward(go.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=2e-5, atol=2e-5)
+    for a, r, name in zip(dev_in, ref_in, "z w b ms".split()):
+        scale = float(r.grad.abs().max()) + 1e-6
+        np.testing.assert_allclose(a.grad.cpu().numpy(), r.grad.numpy(), rtol=2e-4, atol=2e-5 * scale, err_msg=name)
+
+
+def test_graphnorm_dropout_replay_and_rate(dev):
+    from gmlm_amd.ops import GraphNormAct
+    n, f = 2000, 256
+    z = torch.randn(n, f, device=dev, requires_grad=True)
+    one, zero = torch.ones(f, device=dev), torch.zeros(f, device=dev)
+    y0 = GraphNormAct.apply(z, one, zero, one, 1e-5, False, 0.0, 0, torch.float32, None, None)
+    y1 = GraphNormAct.apply(z, one, zero, one, 1e-5, False, 0.3, 1234, torch.float32, None, None)
+    y2 = GraphNormAct.apply(z, one, zero, one, 1e-5, False, 0.3, 1234, torch.float32, None, None)
+    assert torch.equal(y1, y2)                                  # same seed -> same mask (checkpoint replay)
+    kept = (y1 != 0)
+    assert abs(kept.float().mean().item() - 0.7) < 0.01
+    assert torch.allclose(y1[kept], y0[kept] / 0.7, rtol=1e-5, atol=1e-6)
+    y1.sum().backward()                                          # backward regenerates the same mask
+    g1 = z.grad.clone()
+    assert torch.isfinite(g1).all()
+
+
+# ------------------------------------------------------------------------------------------- K6
+@pytest.mark.parametrize("rows,f,act,dt", [(5, 64, False, torch.float32), (300, 768, False, torch.float32),
+                                           (300, 768, True, torch.float32), (257, 256, False, torch.bfloat16),
+                                           (64, 1024, True, torch.float32)])
+def test_bias_res_layernorm(dev, rows, f, act, dt):
+    from gmlm_amd.ops import bias_res_layernorm
+    g = torch.Generator().manual_seed(rows + f)
+    x, res = torch.randn(rows, f, generator=g), torch.randn(rows, f, generator=g)
+    bias, gamma, beta = 0.1 * torch.randn(f, generator=g), 1 + 0.1 * torch.randn(f, generator=g), 0.1 * torch.randn(f, generator=g)
+    go = torch.randn(rows, f, generator=g)
+    eps = 1e-12
+    xq, rq = x.to(dt).float(), res.to(dt).float()
+    ref_in = [v.clone().requires_grad_(True) for v in (xq, bias, rq, gamma, beta)]
+    yr = F.layer_norm(ref_in[0] + ref_in[1] + ref_in[2], (f,), ref_in[3], ref_in[4], eps)
+    if act:
+        yr = F.gelu(yr)
+    yr.backward(go)
+    dev_in = [x.to(dev, dt).requires_grad_(True), bias.to(dev).requires_grad_(True), res.to(dev, dt).requires_grad_(True),
+              gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)]
+    y = bias_res_layernorm(dev_in[0], dev_in[1], dev_in[2], dev_in[3], dev_in[4], eps, act)
+    y.backward(go.to(dev, dt))
+    tol = dict(rtol=2e-5, atol=2e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), yr.detach().numpy(), **tol)
+    for a, r, name in zip(dev_in, ref_in, "x bias res gamma beta".split()):
+        scale = float(r.grad.abs().max()) + 1e-6
+        gt = dict(rtol=2e-4, atol=3e-5 * scale) if dt == torch.float32 else dict(rtol=3e-2, atol=2e-2 * scale)
+        np.testing.assert_allclose(a.grad.float().cpu().numpy(), r.grad.numpy(), err_msg=name, **gt)
+
+
+# ------------------------------------------------------------------------------------------- K5/K7
+def _attn_ref(q, k, v, kv_len, h, scale):
+    b, lq, hd = q.shape
+    d = hd // h
+    qh, kh, vh = (x.view(b, -1, h, d).transpose(1, 2) for x in (q, k, v))
+    s = (qh @ kh.transpose(-1, -2)) * scale
+    if kv_len is not None:
+        m = torch.arange(k.shape[1])[None, :] >= kv_len[:, None]
+        s = s.masked_fill(m[:, None, None, :], torch.finfo(s.dtype).min)
+    return (s.softmax(-1) @ vh).transpose(1, 2).reshape(b, lq, hd)
+
+
+@pytest.mark.parametrize("b,h,lq,lk,d,masked", [(1, 8, 150, 150, 96, False), (3, 4, 24, 24, 64, True), (2, 12, 130, 130, 64, True),
+                                                (1, 8, 5201, 5201, 96, False), (1, 2, 1, 1, 64, False), (2, 3, 70, 200, 96, True)])
+def test_attention_fwd_bwd_fp32(dev, b, h, lq, lk, d, masked):
+    from gmlm_amd.ops import attention
+    g = torch.Generator().manual_seed(lq * 7 + d)
+    q, k, v = (torch.randn(b, l, h * d, generator=g) for l in (lq, lk, lk))
+    kv_len = None
+    if masked:
+        kv_len = torch.randint(1, lk + 1, (b,), generator=g)
+        kv_len[0] = lk
+        if b > 1:
+            kv_len[1] = 1
+    scale = d ** -0.5
+    go = torch.randn(b, lq, h * d, generator=g)
+    ref_in = [x.clone().requires_grad_(True) for x in (q, k, v)]
+    big = lq * lk > 4_000_000
+    if big:   # keep the CPU reference affordable: forward only on a row subset
+        with torch.no_grad():
+            rows = torch.arange(0, lq, 37)
+            yr = _attn_ref(q[:, rows], k, v, kv_len, h, scale)
+    else:
+        yr = _attn_ref(*ref_in, kv_len, h, scale)
+        yr.backward(go)
+    dev_in = [x.to(dev).requires_grad_(True) for x in (q, k, v)]
+    y = attention(dev_in[0], dev_in[1], dev_in[2], None if kv_len is None else kv_len.to(dev, torch.int32), h, scale)
+    y.backward(go.to(dev))
+    if big:
+        np.testing.assert_allclose(y.detach().cpu()[:, rows].numpy(), yr.numpy(), rtol=1e-4, atol=2e-5)
+        assert all(torch.isfinite(x.grad).all() for x in dev_in)
+        return
+    # exact-f32 MFMA (fmaf chain) + fast exp: 1e-5 absolute on O(1) outputs
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for a, r, name in zip(dev_in, ref_in, "q k v".split()):
+        gr = r.grad
+        if masked and name in ("k", "v"):   # masked keys get exactly zero gradient
+            for bi in range(b):
+                assert float(a.grad[bi, int(kv_len[bi]):].abs().max() if int(kv_len[bi]) < lk else 0.0) == 0.0
+        scale_g = float(gr.abs().max()) + 1e-6
+        np.testing.assert_allclose(a.grad.cpu().numpy(), gr.numpy(), rtol=1e-3, atol=2e-5 * scale_g, err_msg=name)
+
+
+@pytest.mark.parametrize("b,h,l,d", [(4, 12, 128, 64), (1, 8, 700, 96)])
+def test_attention_bf16(dev, b, h, l, d):
+    from gmlm_amd.ops import attention
+    g = torch.Generator().manual_seed(l + d)
+    q, k, v = (torch.randn(b, l, h * d, generator=g).bfloat16() for _ in range(3))
+    kv_len = torch.randint(1, l + 1, (b,), generator=g)
+    go = torch.randn(b, l, h * d, generator=g).bfloat16()
+    ref_in = [x.float().requires_grad_(True) for x in (q, k, v)]
+    yr = _attn_ref(*ref_in, kv_len, h, d ** -0.5)
+    yr.backward(go.float())
+    dev_in = [x.to(dev).requires_grad_(True) for x in (q, k, v)]
+    y = attention(dev_in[0], dev_in[1], dev_in[2], kv_len.to(dev, torch.int32), h, d ** -0.5)
+    y.backward(go.to(dev))
+    # bf16 operands (8-bit mantissa) for P and V with fp32 accumulation: 2e-2 on O(1) outputs
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), yr.detach().numpy(), rtol=3e-2, atol=2e-2)
+    for a, r, name in zip(dev_in, ref_in, "q k v".split()):
+        s = float(r.grad.abs().max())
+        np.testing.assert_allclose(a.grad.float().cpu().numpy(), r.grad.numpy(), rtol=5e-2, atol=3e-2 * s, err_msg=name)
+
+
+def test_attention_fused_qkv_strides_and_small_heads(dev):
+    """q/k/v as strided slices of one [b, l, 3*h*d] buffer (BERT layout); head dim 16 via zero padding."""
+    from gmlm_amd.nn import attention_any_dim
+    b, l, h, d = 2, 40, 4, 16
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(b, l, 3 * h * d, generator=g)
+    kv_len = torch.tensor([40, 7])
+    p = h * d
+    yr = _attn_ref(qkv[..., :p], qkv[..., p:2 * p], qkv[..., 2 * p:], kv_len, h, d ** -0.5)
+    qg = qkv.to(dev)
+    y = attention_any_dim(qg[..., :p], qg[..., p:2 * p], qg[..., 2 * p:], kv_len.to(dev, torch.int32), h, d ** -0.5, 0.0, False)
+    np.testing.assert_allclose(y.cpu().numpy(), yr.numpy(), rtol=1e-4, atol=1e-5)
+    b, l, h, d = 2, 50, 12, 64
+    qkv = torch.randn(b, l, 3 * h * d, generator=g).to(dev)
+    p = h * d
+    from gmlm_amd.ops import attention
+    y1 = attention(qkv[..., :p], qkv[..., p:2 * p], qkv[..., 2 * p:], None, h, 0.125)
+    y2 = attention(qkv[..., :p].contiguous(), qkv[..., p:2 * p].contiguous(), qkv[..., 2 * p:].contiguous(), None, h, 0.125)
+    assert torch.equal(y1, y2)
+
+
+def test_attention_dropout(dev):
+    from gmlm_amd.ops import Attention
+    b, h, l, d = 1, 8, 300, 96
+    g = torch.Generator().manual_seed(9)
+    q, k = (torch.randn(b, l, h * d, generator=g).to(dev) for _ in range(2))
+    v = torch.ones(b, l, h * d, device=dev)
+    # with V = 1 the output is sum_k drop(P)_k: mean 1, and exactly 1 without dropout
+    y0 = Attention.apply(q, k, v, None, h, d ** -0.5, 0.0, 0)
+    assert torch.allclose(y0, torch.ones_like(y0), atol=1e-5)
+    y1 = Attention.apply(q, k, v, None, h, d ** -0.5, 0.3, 77)
+    y2 = Attention.apply(q, k, v, None, h, d ** -0.5, 0.3, 77)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y0)
+    assert abs(y1.mean().item() - 1.0) < 0.02
+    # gradient check of the dropped attention against autograd on the same (recovered) mask
+    qs, ks, vs = (torch.randn(1, 64, 2 * 64, generator=g).to(dev).requires_grad_(True) for _ in range(3))
+    eye_v = torch.zeros(1, 64, 2 * 64, device=dev)
+    eye_v[0, :, :64] = torch.eye(64, device=dev)
+    eye_v[0, :, 64:] = torch.eye(64, device=dev)
+    pd = Attention.apply(qs.detach(), ks.detach(), eye_v, None, 2, 0.125, 0.25, 5).view(1, 64, 2, 64).permute(0, 2, 1, 3)  # dropped P
+    p_full = ((qs.view(1, 64, 2, 64).transpose(1, 2) @ ks.view(1, 64, 2, 64).transpose(1, 2).transpose(-1, -2)) * 0.125).softmax(-1)
+    mask = (pd != 0).float() / 0.75
+    assert torch.allclose(pd, p_full.detach() * mask, atol=1e-5)
+    yr = ((p_full * mask) @ vs.view(1, 64, 2, 64).transpose(1, 2)).transpose(1, 2).reshape(1, 64, 128)
+    go = torch.randn(1, 64, 128, generator=g).to(dev)
+    gr = torch.autograd.grad(yr, (qs, ks, vs), go)
+    y = Attention.apply(qs, ks, vs, None, 2, 0.125, 0.25, 5)
+    gk = torch.autograd.grad(y, (qs, ks, vs), go)
+    for a, r in zip(gk, gr):
+        assert torch.allclose(a, r, rtol=1e-3, atol=2e-5)
+
+
+# ------------------------------------------------------------------------------------------- K8 / K9 / gelu
+def test_meanpool_scatter(dev):
+    from gmlm_amd.ops import MeanPoolScatter
+    b, l, p, n = 5, 17, 768, 40
+    g = torch.Generator().manual_seed(8)
+    hs = torch.randn(b, l, p, generator=g)
+    lens = torch.tensor([17, 1, 5, 9, 2])
+    idx = torch.tensor([3, 39, 0, 11, 12])
+    am = (torch.arange(l)[None] < lens[:, None]).long()
+    hr = hs.clone().requires_grad_(True)
+    ref = torch.zeros(n, p).index_put((idx,), O.masked_mean_pool(hr, am))
+    go = torch.randn(n, p, generator=g)
+    ref.backward(go)
+    hg = hs.to(dev).requires_grad_(True)
+    out = MeanPoolScatter.apply(torch.zeros(n, p, device=dev), hg, lens.to(dev, torch.int32), idx.to(dev))
+    out.backward(go.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(hg.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_softmask_golden_and_grad(dev):
+    import gmlm_amd
+    g = load_golden("g5_funcs")
+    x, m, tok = t(g["sm_x"]).to(dev), t(g["sm_mask"]).to(dev), t(g["sm_tok"]).to(dev).requires_grad_(True)
+    out = gmlm_amd.soft_masking_gnn_input(x, m, tok, 0.7)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["sm_out"], rtol=0, atol=1e-7)
+    out2 = gmlm_amd.soft_masking_gnn_input(x, torch.zeros(40, dtype=torch.bool, device=dev), tok, 0.7)
+    assert np.array_equal(out2.detach().cpu().numpy(), g["sm_out_empty"])
+    go = torch.randn(out.shape, device=dev)
+    out.backward(go)
+    ref = 0.7 * go[m].sum(0, keepdim=True)
+    assert torch.allclose(tok.grad, ref, rtol=1e-5, atol=1e-6)
+    # padded, bf16 output used by the model's first layer
+    o3 = gmlm_amd.soft_masking_gnn_input(x, m, tok, 0.7, torch.bfloat16, 16)
+    assert o3.shape == (40, 16) and float(o3[:, 12:].abs().max()) == 0.0
+    assert torch.allclose(o3[:, :12].float(), out.detach(), rtol=1e-2, atol=1e-2)
+
+
+def test_bias_gelu(dev):
+    from gmlm_amd.ops import bias_gelu
+    g = torch.Generator().manual_seed(4)
+    x, bias, go = torch.randn(333, 3072, generator=g), torch.randn(3072, generator=g), torch.randn(333, 3072, generator=g)
+    xr, br = x.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    F.gelu(xr + br).backward(go)
+    xg, bg = x.to(dev).requires_grad_(True), bias.to(dev).requires_grad_(True)
+    y = bias_gelu(xg, bg)
+    y.backward(go.to(dev))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), F.gelu(x + bias).numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(bg.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_ops_refuse_cpu_tensors():
+    import gmlm_amd
+    from gmlm_amd.ops import RGCNAggregate
+    with pytest.raises(gmlm_amd.GmlmHipError):
+        gmlm_amd.degree(torch.zeros(3, dtype=torch.long), 3)
