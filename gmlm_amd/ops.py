@@ -48,6 +48,66 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().float().contiguous()
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline).
+    Off by default (TIMER is None): the product path records nothing."""
+
+    def __init__(self):
+        self.records = []            # (name, start_event, end_event, meta)
+
+    def span(self, name, **meta):
+        return _Span(self, name, meta)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, meta in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += meta.get("bytes", 0.0)
+            d["flops"] += meta.get("flops", 0.0)
+        return out
+
+
+class _Span:
+    def __init__(self, timer, name, meta):
+        self.timer, self.name, self.meta = timer, name, meta
+
+    def __enter__(self):
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e1 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.timer.records.append((self.name, self.e0, self.e1, self.meta))
+        return False
+
+
+class _NoSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+TIMER: Optional[KernelTimer] = None
+_NOSPAN = _NoSpan()
+
+
+def _span(name, **meta):
+    return TIMER.span(name, **meta) if TIMER is not None else _NOSPAN
+
+
+def spmm_algorithmic_bytes(num_edges, num_segments, out_rows, f, elem, edge_w=False):
+    """every edge reads its source row once (no cache credit) + a 4-byte index,
+    per-segment row pointers, one output row per segment (+ a 4-byte 1/cnt lookup per edge backward)."""
+    return float(num_edges * (f * elem + 4 + (4 if edge_w else 0)) + (num_segments + 1) * 4 + out_rows * f * elem)
+
+
 def draw_seed() -> int:
     """Dropout seed from torch's CPU generator: replayed by torch.utils.checkpoint (RNG state is
     preserved there), costs no device sync."""
@@ -100,11 +160,14 @@ class RGCNAggregate(torch.autograd.Function):
     def forward(ctx, x: torch.Tensor, csr) -> torch.Tensor:
         _cuda(x)
         x = x.contiguous()
-        n, f = x.shape
-        if n != csr.num_nodes:
-            raise ValueError(f"x has {n} rows but the graph has {csr.num_nodes} target nodes")
+        n_src, f = x.shape
+        n = csr.num_nodes
+        if n_src != csr.num_src:
+            raise ValueError(f"x has {n_src} rows but the graph expects {csr.num_src} source rows")
         out = torch.empty(n, csr.r_active * f, dtype=x.dtype, device=x.device)
-        _spmm(x, csr.rowptr, csr.col, None, True, n * csr.r_active, f, out)
+        with _span("spmm_fwd", bytes=spmm_algorithmic_bytes(csr.num_edges, n * csr.r_active, n * csr.r_active, f,
+                                                           x.element_size()), f=f):
+            _spmm(x, csr.rowptr, csr.col, None, True, n * csr.r_active, f, out)
         ctx.csr, ctx.n_src = csr, x.shape[0]
         return out
 
@@ -115,7 +178,9 @@ class RGCNAggregate(torch.autograd.Function):
         n, rf = gh.shape
         f = rf // csr.r_active
         gx = torch.empty(csr.num_src, f, dtype=gh.dtype, device=gh.device)
-        _spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, csr.num_src, f, gx)
+        with _span("spmm_bwd", bytes=spmm_algorithmic_bytes(csr.num_edges, csr.num_src, csr.num_src, f, gh.element_size(),
+                                                           True), f=f):
+            _spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, csr.num_src, f, gx)
         return gx, None
 
 
@@ -285,8 +350,9 @@ class Attention(torch.autograd.Function):
         qs, ks, vs = _rows_view(q, h, d), _rows_view(k, h, d), _rows_view(v, h, d)
         out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
         lse = torch.empty(b, h, lq, dtype=torch.float32, device=q.device)
-        check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
-                                       float(p), seed, _ptr(out), _ptr(lse), _dt(q), _stream()), "gmlm_attention_fwd")
+        with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * lq * lk * d):
+            check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
+                                           float(p), seed, _ptr(out), _ptr(lse), _dt(q), _stream()), "gmlm_attention_fwd")
         ctx.save_for_backward(q, k, v, out, lse, kv_len)
         ctx.cfg = (h, float(scale), float(p), seed)
         return out
@@ -304,9 +370,11 @@ class Attention(torch.autograd.Function):
         dk = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
         dv = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
         ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, h, lq, lk, d), q.device)
-        check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h, lq,
-                                       lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, _ptr(dq), _ptr(dk),
-                                       _ptr(dv), hd, hd, hd, _dt(q), _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
+        with _span("attn_bwd_d%d" % d, flops=10.0 * b * h * lq * lk * d):
+            check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
+                                           lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, _ptr(dq),
+                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), _ptr(ws), ws.numel(), _stream()),
+                  "gmlm_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
 
 
