@@ -67,7 +67,7 @@ def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtyp
     cfg = plm.config
     emb = plm.embeddings
     b, l = input_ids.shape
-    x = emb.word_embeddings.weight[input_ids.long()]
+    x = torch.nn.functional.embedding(input_ids.long(), emb.word_embeddings.weight)   # bit-exact row gather
     x = x + emb.token_type_embeddings.weight[0]
     x = x + emb.position_embeddings.weight[:l].unsqueeze(0)
     eps = cfg.layer_norm_eps

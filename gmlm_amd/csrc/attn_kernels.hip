@@ -240,22 +240,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------
 // backward: delta[b,h,q] = sum_d dO * O
 // ------------------------------------------------------------------------------------------------
+// a group of d/V lanes owns one (b, q, h) row: the wave reads 64 x 16 contiguous bytes per instruction
 template <typename T>
-__global__ void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout, int64_t rows /* b*lq*h */, int d,
-                                  int64_t lq, int64_t hn, float* __restrict__ delta) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b, q, h) flat, matches o layout
-  if (i >= rows) return;
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+                                                          int64_t rows /* b*lq*h */, int d, int64_t lq, int64_t hn,
+                                                          float* __restrict__ delta) {
   constexpr int V = Store<T>::kVec;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lanes = d / V <= 8 ? 8 : (d / V <= 16 ? 16 : 32);
+  const int64_t row = gid / lanes;
+  const int c = (int)(gid % lanes);
   float acc = 0.f;
-  for (int c = 0; c < d / V; ++c) {
+  if (row < rows && c < d / V) {
     float a[V], g[V];
-    Store<T>::ldv(o + i * d + c * V, a);
-    Store<T>::ldv(dout + i * d + c * V, g);
+    Store<T>::ldv(o + row * d + c * V, a);
+    Store<T>::ldv(dout + row * d + c * V, g);
 #pragma unroll
     for (int v = 0; v < V; ++v) acc += a[v] * g[v];
   }
-  const int64_t hd = i % hn, bq = i / hn, q = bq % lq, b = bq / lq;
-  delta[(b * hn + hd) * lq + q] = acc;
+  for (int off = lanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (row < rows && c == 0) {
+    const int64_t hd = row % hn, bq = row / hn, q = bq % lq, b = bq / lq;
+    delta[(b * hn + hd) * lq + q] = acc;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,10 +481,15 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
   p.drop_thresh = dropout_threshold(dropout_p); p.keep_scale = 1.f / (1.f - dropout_p); p.seed = seed;
   const int64_t rows = b * lq * h;
-  if (dtype == GMLM_BF16)
-    attn_delta_kernel<bf16_t><<<(int)cdiv(rows, 256), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)dout, rows, (int)d, lq, h, p.delta);
-  else
-    attn_delta_kernel<float><<<(int)cdiv(rows, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
+  {
+    const int cpr = (int)d / (dtype == GMLM_BF16 ? 8 : 4);
+    const int lanes = cpr <= 8 ? 8 : (cpr <= 16 ? 16 : 32);
+    const int64_t threads = rows * lanes;
+    if (dtype == GMLM_BF16)
+      attn_delta_kernel<bf16_t><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)dout, rows, (int)d, lq, h, p.delta);
+    else
+      attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
+  }
   GMLM_LAUNCH_CHECK();
   dim3 gq((unsigned)cdiv(lq, 128), (unsigned)(b * h));
   GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, gq, st, p);

@@ -110,11 +110,27 @@ __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, row cached in registers (<= 4 chunks of 16 B per lane)
+// LayerNorm: one wave per row, row cached in registers (CH chunks of 16 B per lane, CH <= 4).
+// gamma / beta / bias are the same for every row a lane touches (its columns are fixed), so they
+// are loaded once per wave with 16-byte loads and kept in registers.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLnMaxCh = 4;
 
-template <typename T, bool ACT>
+template <int V>
+__device__ __forceinline__ void load_param(const float* __restrict__ p, int col, float (&o)[V], float fill) {
+  if (p) {
+#pragma unroll
+    for (int v = 0; v < V; v += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + col + v);
+      o[v] = t.x; o[v + 1] = t.y; o[v + 2] = t.z; o[v + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < V; ++v) o[v] = fill;
+  }
+}
+
+template <typename T, int CH, bool ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                       const T* __restrict__ res, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int64_t rows, int f, float eps,
@@ -123,55 +139,62 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   constexpr int V = Store<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int nch = f / V;
+  float gm[CH][V], bt[CH][V], bi[CH][V];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nch) {
+      load_param<V>(gamma, ch * V, gm[c], 1.f);
+      load_param<V>(beta, ch * V, bt[c], 0.f);
+      load_param<V>(bias, ch * V, bi[c], 0.f);
+    }
+  }
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_f = 1.f / (float)f;
   for (int64_t r = wave0; r < rows; r += nwaves) {
-    float z[kLnMaxCh][V];
+    float z[CH][V];
     float sum = 0.f;
 #pragma unroll
-    for (int c = 0; c < kLnMaxCh; ++c) {
+    for (int c = 0; c < CH; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nch) {
         const int64_t off = r * f + (int64_t)ch * V;
         Store<T>::ldv(x + off, z[c]);
+        float rr[V];
+        if (res) Store<T>::ldv(res + off, rr);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          if (bias) z[c][v] += bias[ch * V + v];
+          z[c][v] += bi[c][v];
           if (thresh) z[c][v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
+          if (res) z[c][v] += rr[v];
+          sum += z[c][v];
         }
-        if (res) {
-          float rr[V];
-          Store<T>::ldv(res + off, rr);
-#pragma unroll
-          for (int v = 0; v < V; ++v) z[c][v] += rr[v];
-        }
-#pragma unroll
-        for (int v = 0; v < V; ++v) sum += z[c][v];
       }
     }
-    const float mu = wave_sum(sum) / (float)f;
+    const float mu = wave_sum(sum) * inv_f;
     float sq = 0.f;
 #pragma unroll
-    for (int c = 0; c < kLnMaxCh; ++c)
+    for (int c = 0; c < CH; ++c)
       if (c * 64 + lane < nch)
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const float d = z[c][v] - mu;
           sq += d * d;
         }
-    const float rs = 1.f / sqrtf(wave_sum(sq) / (float)f + eps);
+    const float rs = 1.f / sqrtf(wave_sum(sq) * inv_f + eps);
     if (lane == 0) {
       if (mean_o) mean_o[r] = mu;
       if (rstd_o) rstd_o[r] = rs;
     }
 #pragma unroll
-    for (int c = 0; c < kLnMaxCh; ++c) {
+    for (int c = 0; c < CH; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nch) {
         float o[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          float t = (z[c][v] - mu) * rs * gamma[ch * V + v] + beta[ch * V + v];
+          const float t = (z[c][v] - mu) * rs * gm[c][v] + bt[c][v];
           o[v] = ACT ? gelu_erf(t) : t;
         }
         Store<T>::stv(y + r * f + (int64_t)ch * V, o);
@@ -180,9 +203,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
-// backward: each wave keeps per-lane partial dgamma/dbeta/dbias for its fixed columns
-// and writes partial[wave][3][f]; a second kernel sums the waves in order (deterministic).
-template <typename T, bool ACT>
+// backward: each wave keeps per-lane partial dgamma/dbeta/dbias for its fixed columns and writes
+// partial[wave][3][f]; a second kernel sums the waves in a fixed tree order (deterministic).
+template <typename T, int CH, bool ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ bias, const T* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -192,57 +215,56 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   constexpr int V = Store<T>::kVec;
   const int lane = threadIdx.x & 63;
   const int nch = f / V;
-  float dg[kLnMaxCh][V], db[kLnMaxCh][V], dbi[kLnMaxCh][V];
+  float gm[CH][V], bt[CH][V], bi[CH][V];
+  float dg[CH][V], db[CH][V], dbi[CH][V];
 #pragma unroll
-  for (int c = 0; c < kLnMaxCh; ++c)
+  for (int c = 0; c < CH; ++c) {
+    const int ch = c * 64 + lane;
+    if (ch < nch) {
+      load_param<V>(gamma, ch * V, gm[c], 1.f);
+      load_param<V>(beta, ch * V, bt[c], 0.f);
+      load_param<V>(bias, ch * V, bi[c], 0.f);
+    }
 #pragma unroll
     for (int v = 0; v < V; ++v) dg[c][v] = db[c][v] = dbi[c][v] = 0.f;
+  }
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
+  const float inv_f = 1.f / (float)f;
   for (int64_t r = wave0; r < rows; r += nwaves) {
     const float mu = mean[r], rs = rstd[r];
-    float zh[kLnMaxCh][V], dzh[kLnMaxCh][V], dm[kLnMaxCh][V];
+    float zh[CH][V], dzh[CH][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < kLnMaxCh; ++c) {
+    for (int c = 0; c < CH; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nch) {
         const int64_t off = r * f + (int64_t)ch * V;
-        float xv[V], gv[V];
-        Store<T>::ldv(x + off, xv);
+        float gv[V], rr[V];
+        Store<T>::ldv(x + off, zh[c]);
         Store<T>::ldv(dy + off, gv);
+        if (res) Store<T>::ldv(res + off, rr);
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          float z = xv[v];
-          if (bias) z += bias[ch * V + v];
-          dm[c][v] = thresh ? dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale) : 1.f;
-          z *= dm[c][v];
+          float z = zh[c][v] + bi[c][v];
+          if (thresh) z *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
+          if (res) z += rr[v];
+          z = (z - mu) * rs;
           zh[c][v] = z;
-        }
-        if (res) {
-          float rr[V];
-          Store<T>::ldv(res + off, rr);
-#pragma unroll
-          for (int v = 0; v < V; ++v) zh[c][v] += rr[v];
-        }
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          zh[c][v] = (zh[c][v] - mu) * rs;
-          const float gm = gamma[ch * V + v];
           float dyn = gv[v];
-          if (ACT) dyn *= gelu_erf_grad(zh[c][v] * gm + beta[ch * V + v]);
-          dg[c][v] += dyn * zh[c][v];
+          if (ACT) dyn *= gelu_erf_grad(z * gm[c][v] + bt[c][v]);
+          dg[c][v] += dyn * z;
           db[c][v] += dyn;
-          dzh[c][v] = dyn * gm;
+          dzh[c][v] = dyn * gm[c][v];
           s1 += dzh[c][v];
-          s2 += dzh[c][v] * zh[c][v];
+          s2 += dzh[c][v] * z;
         }
       }
     }
-    s1 = wave_sum(s1) / (float)f;
-    s2 = wave_sum(s2) / (float)f;
+    s1 = wave_sum(s1) * inv_f;
+    s2 = wave_sum(s2) * inv_f;
 #pragma unroll
-    for (int c = 0; c < kLnMaxCh; ++c) {
+    for (int c = 0; c < CH; ++c) {
       const int ch = c * 64 + lane;
       if (ch < nch) {
         const int64_t off = r * f + (int64_t)ch * V;
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           dz[v] = rs * (dzh[c][v] - s1 - zh[c][v] * s2);
-          dxv[v] = dz[v] * dm[c][v];
+          dxv[v] = thresh ? dz[v] * dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale) : dz[v];
           dbi[c][v] += dxv[v];
         }
         Store<T>::stv(dx + off, dxv);
@@ -258,34 +280,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // per-wave partials (fixed columns per lane) -> workspace; summed in wave order by the final kernel
   float* prow = partial + wave0 * 3 * (int64_t)f;
 #pragma unroll
-  for (int c = 0; c < kLnMaxCh; ++c) {
+  for (int c = 0; c < CH; ++c) {
     const int ch = c * 64 + lane;
-    if (ch < nch)
-#pragma unroll
-      for (int v = 0; v < V; ++v) {
-        prow[ch * V + v] = dg[c][v];
-        prow[f + ch * V + v] = db[c][v];
-        prow[2 * f + ch * V + v] = dbi[c][v];
+    if (ch < nch) {
+      *reinterpret_cast<float4*>(prow + ch * V) = make_float4(dg[c][0], dg[c][1], dg[c][2], dg[c][3]);
+      *reinterpret_cast<float4*>(prow + f + ch * V) = make_float4(db[c][0], db[c][1], db[c][2], db[c][3]);
+      *reinterpret_cast<float4*>(prow + 2 * f + ch * V) = make_float4(dbi[c][0], dbi[c][1], dbi[c][2], dbi[c][3]);
+      if constexpr (V == 8) {
+        *reinterpret_cast<float4*>(prow + ch * V + 4) = make_float4(dg[c][4], dg[c][5], dg[c][6], dg[c][7]);
+        *reinterpret_cast<float4*>(prow + f + ch * V + 4) = make_float4(db[c][4], db[c][5], db[c][6], db[c][7]);
+        *reinterpret_cast<float4*>(prow + 2 * f + ch * V + 4) = make_float4(dbi[c][4], dbi[c][5], dbi[c][6], dbi[c][7]);
       }
+    }
   }
 }
 
-__global__ void ln_bwd_final_kernel(const float* __restrict__ partial, int blocks, int f, float* __restrict__ dgamma,
-                                    float* __restrict__ dbeta, float* __restrict__ dbias) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= f) return;
-  float a = 0.f, b = 0.f, d = 0.f;
-  for (int j = 0; j < blocks; ++j) {
-    a += partial[(int64_t)j * 3 * f + c];
-    b += partial[(int64_t)j * 3 * f + f + c];
-    d += partial[(int64_t)j * 3 * f + 2 * f + c];
+// out[c] = sum over `nrows` partial rows of partial[row][c], c in [0, 3f): block = 32 columns x 8 row lanes,
+// each lane sums a strided subset (independent loads in flight), then a fixed-order LDS tree.
+__global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restrict__ partial, int nrows, int f,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dbias) {
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  const int f3 = 3 * f;
+  float acc = 0.f;
+  if (c < f3) {
+    int r = ty;
+    for (; r + 24 < nrows; r += 32) {
+      const float a0 = partial[(int64_t)r * f3 + c], a1 = partial[(int64_t)(r + 8) * f3 + c];
+      const float a2 = partial[(int64_t)(r + 16) * f3 + c], a3 = partial[(int64_t)(r + 24) * f3 + c];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < nrows; r += 8) acc += partial[(int64_t)r * f3 + c];
   }
-  if (dgamma) dgamma[c] = a;
-  if (dbeta) dbeta[c] = b;
-  if (dbias) dbias[c] = d;
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < f3) {
+    const float s = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    float* out = c < f ? dgamma : (c < 2 * f ? dbeta : dbias);
+    if (out) out[c % f] = s;
+  }
 }
 
 static inline int ln_bwd_blocks(int64_t rows) {
@@ -402,10 +439,13 @@ extern "C" int gmlm_bias_res_layernorm_fwd(const void* x, const float* bias, con
   const float ks = 1.f / (1.f - dropout_p);
   const int grid = grid_cap(cdiv(rows, 4));
   hipStream_t st = as_stream(stream);
-#define L(T, A) ln_fwd_kernel<T, A><<<grid, 256, 0, st>>>((const T*)x, bias, (const T*)residual, gamma, beta, rows, (int)f, eps, th, ks, seed, (T*)y, mean, rstd)
+  const int ch = (int)cdiv(f / (dtype == GMLM_F32 ? 4 : 8), 64);
+#define L2(T, C, A) ln_fwd_kernel<T, C, A><<<grid, 256, 0, st>>>((const T*)x, bias, (const T*)residual, gamma, beta, rows, (int)f, eps, th, ks, seed, (T*)y, mean, rstd)
+#define L(T, A) do { if (ch <= 1) L2(T, 1, A); else if (ch == 2) L2(T, 2, A); else L2(T, 4, A); } while (0)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
+#undef L2
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
@@ -434,12 +474,15 @@ extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const 
   const float ks = 1.f / (1.f - dropout_p);
   const int blocks = ln_bwd_blocks(rows);
   float* partial = static_cast<float*>(workspace);
-#define L(T, A) ln_bwd_kernel<T, A><<<blocks, 256, 0, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
+  const int ch = (int)cdiv(f / (dtype == GMLM_F32 ? 4 : 8), 64);
+#define L2(T, C, A) ln_bwd_kernel<T, C, A><<<blocks, 256, 0, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
+#define L(T, A) do { if (ch <= 1) L2(T, 1, A); else if (ch == 2) L2(T, 2, A); else L2(T, 4, A); } while (0)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
+#undef L2
   GMLM_LAUNCH_CHECK();
-  ln_bwd_final_kernel<<<(int)cdiv(f, 256), 256, 0, st>>>(partial, blocks * 4, (int)f, dgamma, dbeta, dbias);
+  ln_bwd_final_kernel<<<(int)cdiv(3 * f, 32), 256, 0, st>>>(partial, blocks * 4, (int)f, dgamma, dbeta, dbias);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }

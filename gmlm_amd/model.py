@@ -148,6 +148,7 @@ class GraphTextLM(nn.Module):
         e3 = run(3, x2)
         e4 = run(4, e3)
         # main.py:317-318 computes x4 + residual_proj3(x2) and discards it: skipped (no effect on outputs or grads)
+        self.multi_scale_fusion.compute_dtype = cd
         return self.multi_scale_fusion([e1, e2, e3, e4])
 
     # ------------------------------------------------------------------------------------------
@@ -180,6 +181,11 @@ class GraphTextLM(nn.Module):
         cd = self._cd()
         idx_h = idx.cpu()
         lens_h = tokens.lens_host[idx_h]
+        # length-bucketed micro-batches: every active node is encoded independently and scattered by its own
+        # index, so the order is free; sorting by token count keeps the padding of each micro-batch small
+        order = torch.argsort(lens_h, descending=True, stable=True)
+        lens_h = lens_h[order]
+        idx = idx[order.to(dev)]
         grad = self.plm_encoder.training or self.training
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
             for s in range(0, a, plm_batch_size):
@@ -206,6 +212,7 @@ class GraphTextLM(nn.Module):
         g = gnn_embeds.unsqueeze(0)
         t = plm_embeds.unsqueeze(0)
         gather = self.dist.all_gather_rows if self.dist is not None else None
+        self.graph_to_text_attn.compute_dtype = self.text_to_graph_attn.compute_dtype = cd
         gnn_attended = self.graph_to_text_attn(g, t, gather)
         text_attended = self.text_to_graph_attn(t, g, gather)
         fn = self.fusion_network

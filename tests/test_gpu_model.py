@@ -173,7 +173,9 @@ def _oracle_vs_hip(dev, name, hc, plm, cd, atol, max_len=24, bs=32):
             assert (r is None or float(r.abs().max()) == 0) and (p.grad is None or float(p.grad.abs().max()) == 0), k
             continue
         rn, gn = float(r.double().norm()), float(p.grad.double().norm())
-        assert abs(rn - gn) <= rel * max(rn, 1e-4) + 1e-6, (k, gn, rn)
+        # gradients that are analytically ~0 (e.g. a key bias under softmax) are pure rounding noise: floor the scale
+        floor = 1e-4 if cd == torch.float32 else 2e-3
+        assert abs(rn - gn) <= rel * max(rn, floor) + 1e-6, (k, gn, rn)
     return float(loss), float(loss_ref)
 
 
