@@ -136,6 +136,71 @@ def cpu_baseline(args, data, ids, am):
                 seconds_measured=round(t_rest + t_plm, 1))
 
 
+def _time_events(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return sum(ts) / len(ts), ts[len(ts) // 2]
+
+
+def micro(dev, args):
+    """Kernel micro-benchmarks at sizes where the named roofline is the binding one:
+    * aggregation on a power-law graph whose feature matrix is far larger than the 256 MiB Infinity Cache
+      (a per-GPU shard of the 10M-node S5 config), F=768;
+    * BERT-geometry masked MHA at L=512 (B=32, h=12, d=64) and CrossAttention geometry (h=8, d=96)."""
+    import gmlm_amd
+    from gmlm_amd import ops
+    out = {}
+    g = torch.Generator(device=dev).manual_seed(5)
+    n, e, f = args.micro_nodes, args.micro_edges, 768
+    w = (torch.arange(n, device=dev, dtype=torch.float32) + 1.0).pow(-1.0 / 1.2)          # Chung-Lu, alpha = 2.2
+    perm = torch.randperm(n, device=dev, generator=g)
+    src = perm[torch.multinomial(w, e, replacement=True, generator=g)]
+    dst = perm[torch.multinomial(w, e, replacement=True, generator=g)]
+    ei = torch.stack([src, dst])
+    del w, perm, src, dst
+    csr = gmlm_amd.build_rel_csr(ei, n, 5)
+    for dt, name in ((torch.bfloat16, "bf16"), (torch.float32, "f32")):
+        x = torch.randn(n, f, device=dev, dtype=dt)
+        s_fwd = n * csr.r_active
+        a_fwd = ops.spmm_algorithmic_bytes(e, s_fwd, s_fwd, f, x.element_size())
+        avg, med = _time_events(lambda: ops.RGCNAggregate.apply(x, csr), 5)
+        out[f"spmm_fwd_{name}"] = {"nodes": n, "edges": e, "f": f, "r_active": csr.r_active, "avg_ms": round(avg, 3),
+                                   "algorithmic_GB": round(a_fwd / 1e9, 2), "GBps": round(a_fwd / avg / 1e6, 1),
+                                   "frac_hbm_peak": round(a_fwd / avg / 1e6 / HBM_PEAK_GBS, 4)}
+        gh = torch.randn(n, csr.r_active * f, device=dev, dtype=dt)
+        gx = torch.empty(n, f, device=dev, dtype=dt)
+        a_bwd = ops.spmm_algorithmic_bytes(e, n, n, f, x.element_size(), True)
+        avg, med = _time_events(lambda: ops._spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, n, f, gx), 5)
+        out[f"spmm_bwd_{name}"] = {"avg_ms": round(avg, 3), "algorithmic_GB": round(a_bwd / 1e9, 2),
+                                   "GBps": round(a_bwd / avg / 1e6, 1), "frac_hbm_peak": round(a_bwd / avg / 1e6 / HBM_PEAK_GBS, 4)}
+        del x, gh, gx
+    del csr, ei
+    torch.cuda.empty_cache()
+    for tag, b, h, l, d, masked in (("mha_L512", 32, 12, 512, 64, True), ("mha_L128", 256, 12, 128, 64, True),
+                                    ("xattn_N5201", 1, 8, 5201, 96, False), ("xattn_N20804", 1, 8, 20804, 96, False)):
+        q, k, v = (torch.randn(b, l, h * d, device=dev, dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
+        kv_len = torch.randint(l // 2, l + 1, (b,), device=dev, dtype=torch.int32) if masked else None
+        go = torch.randn(b, l, h * d, device=dev, dtype=torch.bfloat16)
+        fl = 4.0 * b * h * l * l * d
+        avg, _ = _time_events(lambda: ops.attention(q.detach(), k.detach(), v.detach(), kv_len, h, d ** -0.5), 5)
+        y = ops.attention(q, k, v, kv_len, h, d ** -0.5)
+        avg_b, _ = _time_events(lambda: torch.autograd.grad(y, (q, k, v), go, retain_graph=True), 5)
+        out[tag] = {"b": b, "h": h, "l": l, "d": d, "fwd_ms": round(avg, 3), "fwd_TFLOPs": round(fl / avg / 1e9, 1),
+                    "fwd_frac_mfma_peak": round(fl / avg / 1e9 / MFMA_BF16_PEAK_TF, 4), "bwd_ms": round(avg_b, 3),
+                    "bwd_TFLOPs": round(2.5 * fl / avg_b / 1e9, 1),
+                    "bwd_frac_mfma_peak": round(2.5 * fl / avg_b / 1e9 / MFMA_BF16_PEAK_TF, 4),
+                    "note": "padded flops (masked keys counted)" if masked else "no mask"}
+        del q, k, v, go, y
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +218,10 @@ def main():
     ap.add_argument("--cpu-plm-sample", type=int, default=16)
     ap.add_argument("--cpu-hc", type=int, default=768)
     ap.add_argument("--no-kernel-timers", action="store_true")
+    ap.add_argument("--micro", action="store_true", help="also run the kernel micro-benchmarks (rank 0, N=1)")
+    ap.add_argument("--micro-only", action="store_true")
+    ap.add_argument("--micro-nodes", type=int, default=1_250_000)
+    ap.add_argument("--micro-edges", type=int, default=12_500_000)
     args = ap.parse_args()
 
     import gmlm_amd
@@ -170,6 +239,9 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.micro_only:
+        print(json.dumps({"micro": micro(dev, args)}))
+        return
     data = synthetic(args.workload, n_parts=world)
     ids, am = synthetic_tokens(data["n"], args.max_len, args.vocab, seed=data["n"])
     model = build_model(args, data, dev)
@@ -252,6 +324,10 @@ def main():
                                "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                                "avg_launch_ms": round(s["ms"] / s["launches"], 4)}
         out["kernels"] = kern
+    if rank == 0 and world == 1 and args.micro:
+        del model
+        torch.cuda.empty_cache()
+        out["micro"] = micro(dev, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args, data, ids, am)

@@ -158,17 +158,64 @@ __device__ __forceinline__ void store_t(T* rowptr /* + db*32 applied */, const f
 
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
 
+// register-staged tile: global -> registers (issued early, latency hidden under the MFMAs of the
+// current tile) -> LDS (written after the compute; the buffer being written was last read one
+// iteration ago, behind a barrier).  One barrier per tile with two LDS buffers (bf16); the exact-f32
+// parity path keeps one buffer (LDS budget) and two barriers.
+template <typename T, int D, int ROWS, int NT>
+struct TileRegs {
+  static constexpr int V = Store<T>::kVec, CPR = D / V, TOTAL = ROWS * CPR, PER = (TOTAL + NT - 1) / NT,
+                       PITCH = D + Pad<T>::v;
+  uint4 v[PER];
+  __device__ __forceinline__ void load(const T* g, int64_t g_stride, int64_t row0, int64_t limit, int tid) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      const int row = i / CPR, c = i % CPR;
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (i < TOTAL && row0 + row < limit) v[k] = *reinterpret_cast<const uint4*>(g + (row0 + row) * g_stride + c * V);
+    }
+  }
+  __device__ __forceinline__ void store(T* ts, int tid) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT;
+      const int row = i / CPR, c = i % CPR;
+      if (i < TOTAL) *reinterpret_cast<uint4*>(ts + row * PITCH + c * V) = v[k];
+    }
+  }
+};
+
+// attention-probability dropout: one 32-bit hash word decides TWO adjacent keys (16-bit thresholds), so the
+// per-element cost next to the MFMAs is ~1 integer multiply.  word = f(seed, (b,h,q), key >> 1); the
+// same function is evaluated by forward, dQ and dK/dV kernels (nothing is stored).
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_word(uint32_t seed, uint32_t qmix, uint32_t keypair) {
+  return lowbias32((qmix + keypair * 0x85EBCA77u) ^ seed);
+}
+__device__ __forceinline__ float drop_mul16(uint32_t word, int half, uint32_t th16, float ks) {
+  return ((word >> (16 * half)) & 0xFFFFu) >= th16 ? ks : 0.f;
+}
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 // ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  constexpr int KT = 64, PITCH = D + Pad<T>::v, DB = D / 32;
-  __shared__ __attribute__((aligned(16))) T ks[KT * PITCH];
-  __shared__ __attribute__((aligned(16))) T vs[KT * PITCH];
+template <typename T, int D, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
+  constexpr bool DBUF = sizeof(T) == 2;
+  constexpr int KT = 64, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T ks[NBUF][KT * PITCH];
+  __shared__ __attribute__((aligned(16))) T vs[NBUF][KT * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
-  const int64_t q_row = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool q_ok = q_row < p.lq;
   int64_t kvlen = p.lk;
   if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
@@ -182,41 +229,70 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-  float m = -INFINITY, l = 0.f;
-  const uint64_t drop_base = (uint64_t)((b * p.h + hd) * p.lq + q_row) * (uint64_t)p.lk;  // element (b,h,q,key) -> base + key
-  for (int64_t kv0 = 0; kv0 < kvlen; kv0 += KT) {
-    __syncthreads();
-    stage_rows<T, D, KT, 256>(ks, kg, p.k_stride, kv0, p.lk, tid);
-    stage_rows<T, D, KT, 256>(vs, vg, p.v_stride, kv0, p.lk, tid);
-    __syncthreads();
+  float m = -INFINITY, l = 0.f;              // running max / sum in the log2 domain (scores * scale * log2 e)
+  const float sl2 = p.scale * kLog2e;
+  const uint32_t qmix = (uint32_t)((b * p.h + hd) * p.lq + q_row) * 0x9E3779B1u;
+  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
+  const int ntiles = (int)((kvlen + KT - 1) / KT);
+  TileRegs<T, D, KT, NT> kr, vr;
+  if (ntiles > 0) {
+    kr.load(kg, p.k_stride, 0, p.lk, tid);
+    vr.load(vg, p.v_stride, 0, p.lk, tid);
+    kr.store(ks[0], tid);
+    vr.store(vs[0], tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int64_t kv0 = (int64_t)t * KT;
+    const int cur = DBUF ? (t & 1) : 0;
+    const bool more = t + 1 < ntiles;
+    if (DBUF && more) {
+      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+    }
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-      mma_rows<D>(ks, PITCH, kb * 32, qf, s[kb], r, h);
+      mma_rows<D>(ks[cur], PITCH, kb * 32, qf, s[kb], r, h);
     }
     float rmax = -INFINITY;
+    if (kv0 + KT <= kvlen) {                        // whole tile valid (block-uniform): no per-key compare
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int64_t key = kv0 + kb * 32 + acc_row(i, h);
-        const float v = key < kvlen ? s[kb][i] * p.scale : -INFINITY;
-        s[kb][i] = v;
-        rmax = fmaxf(rmax, v);
-      }
+        for (int i = 0; i < 16; ++i) rmax = fmaxf(rmax, s[kb][i]);
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t key = kv0 + kb * 32 + acc_row(i, h);
+          const float v = key < kvlen ? s[kb][i] : -INFINITY;
+          s[kb][i] = v;
+          rmax = fmaxf(rmax, v);
+        }
+    }
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    const float m_new = fmaxf(m, rmax);            // finite: key kv0 is always valid
-    const float alpha = __expf(m - m_new);         // m = -inf -> 0
+    const float m_new = fmaxf(m, rmax * sl2);       // finite: key kv0 is always valid
+    const float alpha = fast_exp2(m - m_new);       // m = -inf -> 0
     float rsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float e = __expf(s[kb][i] - m_new);  // masked -> exp(-inf) = 0
-        rsum += e;                                 // the normaliser uses the un-dropped probabilities
-        s[kb][i] = p.drop_thresh ? e * dropout_scale(p.seed, drop_base + (uint64_t)(kv0 + kb * 32 + acc_row(i, h)), p.drop_thresh, p.keep_scale) : e;
+      for (int i = 0; i < 16; i += 2) {
+        const float e0 = fast_exp2(fmaf(s[kb][i], sl2, -m_new));       // masked: exp2(-inf) = 0
+        const float e1 = fast_exp2(fmaf(s[kb][i + 1], sl2, -m_new));
+        rsum += e0 + e1;                                               // the normaliser uses the un-dropped probabilities
+        if (DROP) {
+          const uint32_t wd = drop_word(seed32, qmix, (uint32_t)((kv0 + kb * 32 + acc_row(i, h)) >> 1));
+          s[kb][i] = e0 * drop_mul16(wd, 0, p.drop_thresh, p.keep_scale);
+          s[kb][i + 1] = e1 * drop_mul16(wd, 1, p.drop_thresh, p.keep_scale);
+        } else {
+          s[kb][i] = e0;
+          s[kb][i + 1] = e1;
+        }
       }
     rsum += __shfl_xor(rsum, 32, 64);
     l = l * alpha + rsum;
@@ -226,14 +302,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) mma_acc<D>(vs, PITCH, kb * 32, s[kb], o, lane);
+    for (int kb = 0; kb < 2; ++kb) mma_acc<D>(vs[cur], PITCH, kb * 32, s[kb], o, lane);
+    if (DBUF) {
+      if (more) {
+        kr.store(ks[cur ^ 1], tid);
+        vr.store(vs[cur ^ 1], tid);
+      }
+      __syncthreads();
+    } else if (more) {
+      __syncthreads();
+      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.store(ks[0], tid);
+      vr.store(vs[0], tid);
+      __syncthreads();
+    }
   }
   if (q_ok) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     T* og = static_cast<T*>(p.o_w) + ((b * p.lq + q_row) * p.h + hd) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
-    if (h == 0 && p.lse_w) p.lse_w[(b * p.h + hd) * p.lq + q_row] = l > 0.f ? m + __logf(l) : -INFINITY;
+    if (h == 0 && p.lse_w) p.lse_w[(b * p.h + hd) * p.lq + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
   }
 }
 
@@ -266,18 +356,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: dQ.  workgroup = 128 queries, loop over key tiles of 32.
+// backward: dQ.  workgroup = NW*32 queries, loop over key tiles.
 //   S^T = K Q^T, P^T = exp(scale*S^T - lse[q]), dP^T = V dO^T, dS^T = P^T*(dP^T - delta[q]),
 //   dQ^T += K^T dS^T  (all with the query on the lane)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-  constexpr int KT = 32, PITCH = D + Pad<T>::v, DB = D / 32;
-  __shared__ __attribute__((aligned(16))) T ks[KT * PITCH];
-  __shared__ __attribute__((aligned(16))) T vs[KT * PITCH];
+template <typename T, int D, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
+  constexpr bool DBUF = sizeof(T) == 2;
+  constexpr int KT = DBUF ? 64 : 32, KB = KT / 32, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T ks[NBUF][KT * PITCH];
+  __shared__ __attribute__((aligned(16))) T vs[NBUF][KT * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
-  const int64_t q_row = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool q_ok = q_row < p.lq;
   int64_t kvlen = p.lk;
   if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
@@ -287,32 +378,63 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   RowFrag<T, D> qf, dof;
   qf.load(static_cast<const T*>(p.q) + (b * p.lq + qr) * p.q_stride + hd * D, q_ok, h);
   dof.load(static_cast<const T*>(p.dout) + ((b * p.lq + qr) * p.h + hd) * D, q_ok, h);
-  const float lse = q_ok ? p.lse[(b * p.h + hd) * p.lq + q_row] : 0.f;
+  const float sl2 = p.scale * kLog2e;
+  const float lse2 = q_ok ? p.lse[(b * p.h + hd) * p.lq + q_row] * kLog2e : 0.f;
   const float dl = q_ok ? p.delta[(b * p.h + hd) * p.lq + q_row] : 0.f;
-  const uint64_t drop_base = (uint64_t)((b * p.h + hd) * p.lq + q_row) * (uint64_t)p.lk;
+  const uint32_t qmix = (uint32_t)((b * p.h + hd) * p.lq + q_row) * 0x9E3779B1u;
+  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   f32x16 dq[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
-  for (int64_t kv0 = 0; kv0 < kvlen; kv0 += KT) {
-    __syncthreads();
-    stage_rows<T, D, KT, 256>(ks, kg, p.k_stride, kv0, p.lk, tid);
-    stage_rows<T, D, KT, 256>(vs, vg, p.v_stride, kv0, p.lk, tid);
-    __syncthreads();
-    f32x16 s, dp;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-    mma_rows<D>(ks, PITCH, 0, qf, s, r, h);
-    mma_rows<D>(vs, PITCH, 0, dof, dp, r, h);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int64_t key = kv0 + acc_row(i, h);
-      const float pr = (key < kvlen && q_ok) ? __expf(s[i] * p.scale - lse) : 0.f;
-      const float ms = p.drop_thresh ? dropout_scale(p.seed, drop_base + (uint64_t)key, p.drop_thresh, p.keep_scale) : 1.f;
-      s[i] = pr * (dp[i] * ms - dl);
+  const int ntiles = (int)((kvlen + KT - 1) / KT);
+  TileRegs<T, D, KT, NT> kr, vr;
+  if (ntiles > 0) {
+    kr.load(kg, p.k_stride, 0, p.lk, tid);
+    vr.load(vg, p.v_stride, 0, p.lk, tid);
+    kr.store(ks[0], tid);
+    vr.store(vs[0], tid);
+  }
+  __syncthreads();
+  for (int t = 0; t < ntiles; ++t) {
+    const int64_t kv0 = (int64_t)t * KT;
+    const int cur = DBUF ? (t & 1) : 0;
+    const bool more = t + 1 < ntiles;
+    if (DBUF && more) {
+      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
     }
-    mma_acc<D>(ks, PITCH, 0, s, dq, lane);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      mma_rows<D>(ks[cur], PITCH, kb * 32, qf, s, r, h);
+      mma_rows<D>(vs[cur], PITCH, kb * 32, dof, dp, r, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t key = kv0 + kb * 32 + acc_row(i, h);
+        const float pr = (key < kvlen && q_ok) ? fast_exp2(fmaf(s[i], sl2, -lse2)) : 0.f;
+        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        s[i] = pr * (dp[i] * ms - dl);
+      }
+      mma_acc<D>(ks[cur], PITCH, kb * 32, s, dq, lane);
+    }
+    if (DBUF) {
+      if (more) {
+        kr.store(ks[cur ^ 1], tid);
+        vr.store(vs[cur ^ 1], tid);
+      }
+      __syncthreads();
+    } else if (more) {
+      __syncthreads();
+      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.store(ks[0], tid);
+      vr.store(vs[0], tid);
+      __syncthreads();
+    }
   }
   if (q_ok) {
     T* og = static_cast<T*>(p.dq) + (b * p.lq + q_row) * p.dq_stride + hd * D;
@@ -326,59 +448,102 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 //   S = Q K^T, P = exp(scale*S - lse[q]), dV^T += dO^T P, dP = dO V^T, dS = P*(dP - delta[q]),
 //   dK^T += Q^T dS   (all with the key on the lane, the query in the accumulator registers)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr int QT = 32, PITCH = D + Pad<T>::v, DB = D / 32;
-  __shared__ __attribute__((aligned(16))) T qs[QT * PITCH];
-  __shared__ __attribute__((aligned(16))) T dos[QT * PITCH];
-  __shared__ float lse_s[QT];
-  __shared__ float dl_s[QT];
+template <typename T, int D, int NW, bool DROP>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
+  constexpr bool DBUF = sizeof(T) == 2;
+  constexpr int QT = 32, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
+  __shared__ __attribute__((aligned(16))) T qs[NBUF][QT * PITCH];
+  __shared__ __attribute__((aligned(16))) T dos[NBUF][QT * PITCH];
+  __shared__ float lse_s[NBUF][QT];
+  __shared__ float dl_s[NBUF][QT];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
   int64_t kvlen = p.lk;
   if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
-  const int64_t key = (int64_t)blockIdx.x * 128 + w * 32 + r;
+  const int64_t key = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool key_in = key < p.lk;           // row exists in memory
   const bool key_ok = key < kvlen;          // takes part in the softmax
-  const int64_t kr = key_in ? key : 0;
+  const int64_t kr_ = key_in ? key : 0;
   RowFrag<T, D> kf, vf;
-  kf.load(static_cast<const T*>(p.k) + (b * p.lk + kr) * p.k_stride + hd * D, key_in, h);
-  vf.load(static_cast<const T*>(p.v) + (b * p.lk + kr) * p.v_stride + hd * D, key_in, h);
+  kf.load(static_cast<const T*>(p.k) + (b * p.lk + kr_) * p.k_stride + hd * D, key_in, h);
+  vf.load(static_cast<const T*>(p.v) + (b * p.lk + kr_) * p.v_stride + hd * D, key_in, h);
   const T* qg = static_cast<const T*>(p.q) + b * p.lq * p.q_stride + hd * D;
   const T* dog = static_cast<const T*>(p.dout) + (b * p.lq * p.h + hd) * D;
+  const float* lse_g = p.lse + (b * p.h + hd) * p.lq;
+  const float* dl_g = p.delta + (b * p.h + hd) * p.lq;
+  const float sl2 = p.scale * kLog2e;
+  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   f32x16 dk[DB], dv[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
   // a whole workgroup past kv_len has nothing to accumulate (block-uniform condition)
-  const bool block_live = (int64_t)blockIdx.x * 128 < kvlen;
+  const bool block_live = (int64_t)blockIdx.x * (NW * 32) < kvlen;
   if (block_live) {
-    for (int64_t q0 = 0; q0 < p.lq; q0 += QT) {
-      __syncthreads();
-      stage_rows<T, D, QT, 256>(qs, qg, p.q_stride, q0, p.lq, tid);
-      stage_rows<T, D, QT, 256>(dos, dog, p.h * D, q0, p.lq, tid);
+    const int ntiles = (int)((p.lq + QT - 1) / QT);
+    TileRegs<T, D, QT, NT> qr, dor;
+    float lr = 0.f, dr = 0.f;
+    auto load_small = [&](int64_t q0) {
       if (tid < QT) {
         const bool ok = q0 + tid < p.lq;
-        lse_s[tid] = ok ? p.lse[(b * p.h + hd) * p.lq + q0 + tid] : 0.f;
-        dl_s[tid] = ok ? p.delta[(b * p.h + hd) * p.lq + q0 + tid] : 0.f;
+        lr = ok ? lse_g[q0 + tid] * kLog2e : 0.f;
+        dr = ok ? dl_g[q0 + tid] : 0.f;
       }
-      __syncthreads();
+    };
+    auto store_small = [&](int buf) {
+      if (tid < QT) { lse_s[buf][tid] = lr; dl_s[buf][tid] = dr; }
+    };
+    if (ntiles > 0) {
+      qr.load(qg, p.q_stride, 0, p.lq, tid);
+      dor.load(dog, p.h * D, 0, p.lq, tid);
+      load_small(0);
+      qr.store(qs[0], tid);
+      dor.store(dos[0], tid);
+      store_small(0);
+    }
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+      const int64_t q0 = (int64_t)t * QT;
+      const int cur = DBUF ? (t & 1) : 0;
+      const bool more = t + 1 < ntiles;
+      if (DBUF && more) {
+        qr.load(qg, p.q_stride, q0 + QT, p.lq, tid);
+        dor.load(dog, p.h * D, q0 + QT, p.lq, tid);
+        load_small(q0 + QT);
+      }
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-      mma_rows<D>(qs, PITCH, 0, kf, s, r, h);
-      mma_rows<D>(dos, PITCH, 0, vf, dp, r, h);
+      mma_rows<D>(qs[cur], PITCH, 0, kf, s, r, h);
+      mma_rows<D>(dos[cur], PITCH, 0, vf, dp, r, h);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qi = acc_row(i, h);
-        const float pr = (key_ok && q0 + qi < p.lq) ? __expf(s[i] * p.scale - lse_s[qi]) : 0.f;
-        const float ms = p.drop_thresh ? dropout_scale(p.seed, (uint64_t)((b * p.h + hd) * p.lq + q0 + qi) * (uint64_t)p.lk + (uint64_t)key, p.drop_thresh, p.keep_scale) : 1.f;
+        const float pr = (key_ok && q0 + qi < p.lq) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
+        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)((b * p.h + hd) * p.lq + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
         s[i] = pr * ms;
-        dp[i] = pr * (dp[i] * ms - dl_s[qi]);
+        dp[i] = pr * (dp[i] * ms - dl_s[cur][qi]);
       }
-      mma_acc<D>(dos, PITCH, 0, s, dv, lane);
-      mma_acc<D>(qs, PITCH, 0, dp, dk, lane);
+      mma_acc<D>(dos[cur], PITCH, 0, s, dv, lane);
+      mma_acc<D>(qs[cur], PITCH, 0, dp, dk, lane);
+      if (DBUF) {
+        if (more) {
+          qr.store(qs[cur ^ 1], tid);
+          dor.store(dos[cur ^ 1], tid);
+          store_small(cur ^ 1);
+        }
+        __syncthreads();
+      } else if (more) {
+        __syncthreads();
+        qr.load(qg, p.q_stride, q0 + QT, p.lq, tid);
+        dor.load(dog, p.h * D, q0 + QT, p.lq, tid);
+        load_small(q0 + QT);
+        qr.store(qs[0], tid);
+        dor.store(dos[0], tid);
+        store_small(0);
+        __syncthreads();
+      }
     }
   }
   if (key_in) {
@@ -391,6 +556,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
     }
   }
 }
+
+// 16-bit dropout threshold: P(drop) = th / 65536 (|error| < 8e-6), keep scale uses the quantised rate
+static inline uint32_t drop16(float p) { long t = lroundf(p * 65536.f); return (uint32_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t)); }
 
 static int attn_check(const char* who, int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d, int dtype) {
   GMLM_REQUIRE(b >= 0 && h > 0 && lq >= 0 && lk >= 0, "%s: bad sizes", who);
@@ -411,16 +579,24 @@ static int stride_check(const char* who, const void* ptr, int64_t stride, int64_
 
 using namespace gmlm;
 
-#define GMLM_ATTN_DISPATCH(KERNEL, grid, st, prm)                                   \
-  do {                                                                              \
-    if (dtype == GMLM_BF16) {                                                       \
-      if (d == 64) KERNEL<bf16_t, 64><<<grid, 256, 0, st>>>(prm);                   \
-      else KERNEL<bf16_t, 96><<<grid, 256, 0, st>>>(prm);                           \
-    } else {                                                                        \
-      if (d == 64) KERNEL<float, 64><<<grid, 256, 0, st>>>(prm);                    \
-      else KERNEL<float, 96><<<grid, 256, 0, st>>>(prm);                            \
-    }                                                                               \
+#define GMLM_ATTN_DISPATCH2(KERNEL, NWV, DR, grid, st, prm)                                  \
+  do {                                                                                       \
+    if (dtype == GMLM_BF16) {                                                                \
+      if (d == 64) KERNEL<bf16_t, 64, NWV, DR><<<grid, NWV * 64, 0, st>>>(prm);              \
+      else KERNEL<bf16_t, 96, NWV, DR><<<grid, NWV * 64, 0, st>>>(prm);                      \
+    } else {                                                                                 \
+      if (d == 64) KERNEL<float, 64, NWV, DR><<<grid, NWV * 64, 0, st>>>(prm);               \
+      else KERNEL<float, 96, NWV, DR><<<grid, NWV * 64, 0, st>>>(prm);                       \
+    }                                                                                        \
   } while (0)
+#define GMLM_ATTN_DISPATCH(KERNEL, NWV, grid, st, prm)                                       \
+  do {                                                                                       \
+    if ((prm).drop_thresh) GMLM_ATTN_DISPATCH2(KERNEL, NWV, true, grid, st, prm);            \
+    else GMLM_ATTN_DISPATCH2(KERNEL, NWV, false, grid, st, prm);                             \
+  } while (0)
+
+// 4 waves (128 rows) per workgroup unless that leaves the 256 CUs under-filled: then 2 waves (64 rows)
+static inline int pick_waves(int64_t rows, int64_t bh) { return cdiv(rows, 128) * bh >= 1024 ? 4 : 2; }
 
 extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                                   int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
@@ -428,6 +604,7 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
                                   gmlm_stream_t stream) {
   int rc = attn_check("attention_fwd", b, h, lq, lk, d, dtype);
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_fwd: dropout_p must be in [0,1)");
+  GMLM_REQUIRE(scale > 0.f, "attention_fwd: scale must be positive");
   if (rc != GMLM_OK) return rc;
   if (b == 0 || lq == 0) return GMLM_OK;
   if ((rc = stride_check("attention_fwd(q)", q, q_stride, h * d, dtype)) != GMLM_OK) return rc;
@@ -440,10 +617,15 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.lse_w = lse;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale;
-  p.drop_thresh = dropout_threshold(dropout_p); p.keep_scale = 1.f / (1.f - dropout_p); p.seed = seed;
-  dim3 grid((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+  p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
   hipStream_t st = as_stream(stream);
-  GMLM_ATTN_DISPATCH(attn_fwd_kernel, grid, st, p);
+  if (pick_waves(lq, b * h) == 4) {
+    dim3 grid((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_fwd_kernel, 4, grid, st, p);
+  } else {
+    dim3 grid((unsigned)cdiv(lq, 64), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_fwd_kernel, 2, grid, st, p);
+  }
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
@@ -479,7 +661,7 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.dq = dq; p.dk = dk; p.dv = dv;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
-  p.drop_thresh = dropout_threshold(dropout_p); p.keep_scale = 1.f / (1.f - dropout_p); p.seed = seed;
+  p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
   const int64_t rows = b * lq * h;
   {
     const int cpr = (int)d / (dtype == GMLM_BF16 ? 8 : 4);
@@ -491,11 +673,21 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
-  dim3 gq((unsigned)cdiv(lq, 128), (unsigned)(b * h));
-  GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, gq, st, p);
+  if (pick_waves(lq, b * h) == 4) {
+    dim3 gq((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 4, gq, st, p);
+  } else {
+    dim3 gq((unsigned)cdiv(lq, 64), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 2, gq, st, p);
+  }
   GMLM_LAUNCH_CHECK();
-  dim3 gk((unsigned)cdiv(lk, 128), (unsigned)(b * h));
-  GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, st, p);
+  if (pick_waves(lk, b * h) == 4) {
+    dim3 gk((unsigned)cdiv(lk, 128), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
+  } else {
+    dim3 gk((unsigned)cdiv(lk, 64), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
+  }
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
