@@ -177,7 +177,7 @@ def micro(dev, args):
         gh = torch.randn(n, csr.r_active * f, device=dev, dtype=dt)
         gx = torch.empty(n, f, device=dev, dtype=dt)
         a_bwd = ops.spmm_algorithmic_bytes(e, n, n, f, x.element_size(), True)
-        avg, med = _time_events(lambda: ops._spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, n, f, gx), 5)
+        avg, med = _time_events(lambda: ops._spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, n, f, gx, csr.t_split), 5)
         out[f"spmm_bwd_{name}"] = {"avg_ms": round(avg, 3), "algorithmic_GB": round(a_bwd / 1e9, 2),
                                    "GBps": round(a_bwd / avg / 1e6, 1), "frac_hbm_peak": round(a_bwd / avg / 1e6 / HBM_PEAK_GBS, 4)}
         del x, gh, gx

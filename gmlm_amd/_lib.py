@@ -29,7 +29,8 @@ SIGNATURES = {
     "gmlm_gather_i64_to_i32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "gmlm_gather_i32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "gmlm_segment_inv_count": (C.c_int, [_p, _i64, _p, _p]),
-    "gmlm_rgcn_mean_spmm": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _i64, _i32, _p]),
+    "gmlm_rgcn_mean_spmm": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _i64,
+                                      _p, _p]),
     "gmlm_colstats_workspace_bytes": (_sz, [_i64, _i64]),
     "gmlm_colstats": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_graphnorm_finalize": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _p, _p, _p]),

@@ -22,6 +22,33 @@ from .ops import _cuda, _ptr, _stream, _ws, edge_types_from_degree
 
 
 @dataclass
+class SplitPlan:
+    """Chunking of the long segments of a skewed graph (index data, built once per graph)."""
+    thresh: int
+    long_seg: torch.Tensor      # int32 [n_long]
+    chunk_ptr: torch.Tensor     # int32 [n_long + 1]
+    chunk_owner: torch.Tensor   # int32 [n_chunks]
+    n_long: int
+    n_chunks: int
+
+
+def make_split_plan(rowptr: torch.Tensor, thresh: int = 256) -> Optional[SplitPlan]:
+    lens = (rowptr[1:] - rowptr[:-1]).to(torch.int64)
+    long_seg = (lens > thresh).nonzero(as_tuple=True)[0]          # one small D2H (count) per graph
+    n_long = int(long_seg.numel())
+    if n_long == 0:
+        return None
+    if n_long > 65535:                                            # grid.y limit of the combine kernel: coarser chunks
+        return make_split_plan(rowptr, thresh * 4)
+    nch = (lens[long_seg] + thresh - 1) // thresh
+    chunk_ptr = torch.zeros(n_long + 1, dtype=torch.int64, device=rowptr.device)
+    chunk_ptr[1:] = torch.cumsum(nch, 0)
+    owner = torch.repeat_interleave(torch.arange(n_long, device=rowptr.device), nch)
+    return SplitPlan(thresh, long_seg.to(torch.int32).contiguous(), chunk_ptr.to(torch.int32).contiguous(),
+                     owner.to(torch.int32).contiguous(), n_long, int(owner.numel()))
+
+
+@dataclass
 class RelCSR:
     num_nodes: int            # target rows
     num_src: int              # rows of the source feature matrix (== num_nodes unless halo rows are appended)
@@ -35,6 +62,8 @@ class RelCSR:
     inv_cnt: torch.Tensor     # f32 [N*R_a]
     t_rowptr: torch.Tensor    # int32 [N_src+1]
     t_seg: torch.Tensor       # int32 [E]
+    split: Optional[SplitPlan] = None      # long target segments (forward)
+    t_split: Optional[SplitPlan] = None    # long source segments (backward)
 
     @property
     def r_active(self) -> int:
@@ -106,7 +135,7 @@ def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
         raise ValueError("edge_index / edge_type contain ids outside the graph (targets must be < num_nodes, "
                          "sources < num_src, relations < num_relations)")
     return RelCSR(num_nodes, num_src, e, num_relations, active, edge_type, rowptr, col[:e], perm, inv_cnt[:nseg], t_rowptr,
-                  t_seg[:e])
+                  t_seg[:e], make_split_plan(rowptr), make_split_plan(t_rowptr))
 
 
 class GraphCache:

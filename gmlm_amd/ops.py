@@ -147,9 +147,16 @@ def edge_types_from_degree(edge_index: torch.Tensor, num_nodes: int) -> torch.Te
 # ---------------------------------------------------------------------------------------------
 # K2/K3: relation-segmented mean aggregation
 # ---------------------------------------------------------------------------------------------
-def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out):
+def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out, split=None):
+    """split: optional graph.SplitPlan (long segments of a skewed graph are reduced chunk-wise)."""
+    if split is not None and split.n_long > 0:
+        partial = torch.empty(split.n_chunks, f, dtype=torch.float32, device=src.device)
+        extra = (split.thresh, _ptr(split.long_seg), _ptr(split.chunk_ptr), _ptr(split.chunk_owner), split.n_long,
+                 split.n_chunks, _ptr(partial))
+    else:
+        extra = (0, None, None, None, 0, 0, None)
     check(lib().gmlm_rgcn_mean_spmm(_ptr(src), src.shape[0], src.stride(0), _ptr(rowptr), _ptr(idx), _ptr(edge_w),
-                                    1 if mean else 0, num_segments, f, _ptr(out), f, _dt(src), _stream()),
+                                    1 if mean else 0, num_segments, f, _ptr(out), f, _dt(src), *extra, _stream()),
           "gmlm_rgcn_mean_spmm")
 
 
@@ -167,7 +174,7 @@ class RGCNAggregate(torch.autograd.Function):
         out = torch.empty(n, csr.r_active * f, dtype=x.dtype, device=x.device)
         with _span("spmm_fwd", bytes=spmm_algorithmic_bytes(csr.num_edges, n * csr.r_active, n * csr.r_active, f,
                                                            x.element_size()), f=f):
-            _spmm(x, csr.rowptr, csr.col, None, True, n * csr.r_active, f, out)
+            _spmm(x, csr.rowptr, csr.col, None, True, n * csr.r_active, f, out, csr.split)
         ctx.csr, ctx.n_src = csr, x.shape[0]
         return out
 
@@ -180,7 +187,7 @@ class RGCNAggregate(torch.autograd.Function):
         gx = torch.empty(csr.num_src, f, dtype=gh.dtype, device=gh.device)
         with _span("spmm_bwd", bytes=spmm_algorithmic_bytes(csr.num_edges, csr.num_src, csr.num_src, f, gh.element_size(),
                                                            True), f=f):
-            _spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, csr.num_src, f, gx)
+            _spmm(gh.view(n * csr.r_active, f), csr.t_rowptr, csr.t_seg, csr.inv_cnt, False, csr.num_src, f, gx, csr.t_split)
         return gx, None
 
 

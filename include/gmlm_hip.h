@@ -90,10 +90,18 @@ int gmlm_segment_inv_count(const int32_t* rowptr, int64_t num_segments, float* i
  * Rows of src/out are `*_stride` elements apart.  Deterministic: fixed summation order, no atomics.
  * f % (16 / sizeof(dtype)) == 0 with 16-byte aligned rows takes the vector path; anything else
  * the scalar path.
+ *
+ * Skewed (power-law) graphs: segments longer than `long_threshold` edges are cut into chunks of that
+ * many edges, each chunk is reduced by its own lane group into `partial` (fp32 [n_chunks, f]) and a third
+ * kernel adds the partials of a segment in chunk order (still deterministic).  The plan arrays
+ * (`long_seg` [n_long], `chunk_ptr` [n_long+1], `chunk_owner` [n_chunks]) are index data built once per
+ * graph by the caller; pass long_threshold = 0 / n_long = 0 for no splitting.
  * ------------------------------------------------------------------------------------------- */
 int gmlm_rgcn_mean_spmm(const void* src, int64_t src_rows, int64_t src_stride, const int32_t* rowptr,
                         const int32_t* idx, const float* edge_w, int mean, int64_t num_segments, int64_t f,
-                        void* out, int64_t out_stride, int dtype, gmlm_stream_t stream);
+                        void* out, int64_t out_stride, int dtype, int64_t long_threshold, const int32_t* long_seg,
+                        const int32_t* chunk_ptr, const int32_t* chunk_owner, int64_t n_long, int64_t n_chunks,
+                        float* partial, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K4  GraphNorm (+ exact-erf GELU + dropout) forward / backward, single graph (batch = all rows)

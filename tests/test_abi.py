@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_argument_validation_happens_on_the_host(built):
     """Bad arguments are rejected before any launch, so this is safe without a GPU."""
     lib = built.lib()
-    rc = lib.gmlm_rgcn_mean_spmm(None, 0, 4, None, None, None, 1, 10, 8, None, 8, 0, None)   # stride < f
+    rc = lib.gmlm_rgcn_mean_spmm(None, 0, 4, None, None, None, 1, 10, 8, None, 8, 0, 0, None, None, None, 0, 0, None, None)   # stride < f
     assert rc == -1 and b"stride" in lib.gmlm_last_error()
     rc = lib.gmlm_attention_fwd(None, None, None, None, 1, 8, 16, 16, 128, 1024, 1024, 1024, 1.0, 0.0, 0, None, None, 0, None)
     assert rc == -1 and b"head dim" in lib.gmlm_last_error()
