@@ -38,48 +38,72 @@ def check_supported(plm) -> None:
         raise NotImplementedError("gmlm_amd text-encoder kernels do not cover this PLM: " + "; ".join(problems))
 
 
-def _layer(layer, h, lens, heads, cd, training, p_hidden, p_attn, eps):
-    att = layer.attention
-    sa = att.self
+class LayerWeights:
+    """Per-forward view of one BertLayer's parameters in the compute dtype (QKV fused).  Built ONCE per
+    forward and shared by all micro-batches: the casts / concatenation (and, in backward, the gradient casts
+    back to the fp32 masters) then happen once per step instead of once per micro-batch."""
+
+    def __init__(self, layer, cd):
+        sa, so = layer.attention.self, layer.attention.output
+        c = lambda t: t.to(cd)
+        self.wqkv = c(torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0))
+        self.bqkv = c(torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0))
+        self.wo, self.bo = c(so.dense.weight), so.dense.bias
+        self.ln1w, self.ln1b = so.LayerNorm.weight, so.LayerNorm.bias
+        self.wi, self.bi = c(layer.intermediate.dense.weight), layer.intermediate.dense.bias
+        self.wo2, self.bo2 = c(layer.output.dense.weight), layer.output.dense.bias
+        self.ln2w, self.ln2b = layer.output.LayerNorm.weight, layer.output.LayerNorm.bias
+
+
+def prepare_weights(plm, cd):
+    return [LayerWeights(layer, cd) for layer in plm.encoder.layer]
+
+
+def _mm(x, w, b=None):
+    with torch.autocast("cuda", enabled=False):
+        return torch.nn.functional.linear(x, w, b)
+
+
+def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps):
     pdim = h.shape[-1]
-    wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0)
-    bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0)
-    qkv = _linear(h, wqkv, bqkv)                                                   # [B, L, 3P]
-    scale = (pdim // heads) ** -0.5
-    ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
-                            training)
-    so = att.output
-    a = ops.bias_res_layernorm(_linear(ctx, so.dense.weight), so.dense.bias, h, so.LayerNorm.weight, so.LayerNorm.bias, eps,
-                               False, p_hidden, training)
-    m = ops.bias_gelu(_linear(a, layer.intermediate.dense.weight), layer.intermediate.dense.bias)
-    oo = layer.output
-    return ops.bias_res_layernorm(_linear(m, oo.dense.weight), oo.dense.bias, a, oo.LayerNorm.weight, oo.LayerNorm.bias, eps,
-                                  False, p_hidden, training)
+    d = pdim // heads
+    qkv = _mm(h, lw.wqkv, lw.bqkv)                                                  # [B, L, 3P]
+    scale = d ** -0.5
+    if d in (64, 96):
+        ctx = ops.attention_qkv(qkv, lens, heads, scale, p_attn, training)
+    else:
+        ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
+                                training)
+    a = ops.bias_res_layernorm(_mm(ctx, lw.wo), lw.bo, h, lw.ln1w, lw.ln1b, eps, False, p_hidden, training)
+    m = ops.bias_gelu(_mm(a, lw.wi), lw.bi)
+    return ops.bias_res_layernorm(_mm(m, lw.wo2), lw.bo2, a, lw.ln2w, lw.ln2b, eps, False, p_hidden, training)
 
 
 def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtype, training: bool = False,
-                gradient_checkpointing: bool = False) -> torch.Tensor:
+                gradient_checkpointing: bool = False, weights=None) -> torch.Tensor:
     """input_ids int [B, L] (padding anywhere past ``lens[b]`` is ignored), lens int32 [B] -> [B, L, P] in ``cd``.
 
     Token / position / type gathers are plain index gathers (bit-exact); padded key positions get
     probability 0 in every layer, padded query rows are computed but never read by the pooling.
+    ``weights``: optional ``prepare_weights(plm, cd)`` result shared across micro-batches.
     """
     cfg = plm.config
     emb = plm.embeddings
     b, l = input_ids.shape
     x = torch.nn.functional.embedding(input_ids.long(), emb.word_embeddings.weight)   # bit-exact row gather
-    x = x + emb.token_type_embeddings.weight[0]
-    x = x + emb.position_embeddings.weight[:l].unsqueeze(0)
+    x = x + (emb.token_type_embeddings.weight[0] + emb.position_embeddings.weight[:l]).unsqueeze(0)
     eps = cfg.layer_norm_eps
     p_hidden = cfg.hidden_dropout_prob
     p_attn = cfg.attention_probs_dropout_prob
     h = ops.bias_res_layernorm(x.to(cd), None, None, emb.LayerNorm.weight, emb.LayerNorm.bias, eps, False, p_hidden, training)
     heads = cfg.num_attention_heads
-    for layer in plm.encoder.layer:
+    if weights is None:
+        weights = prepare_weights(plm, cd)
+    for lw in weights:
         if gradient_checkpointing and training and torch.is_grad_enabled():
-            h = checkpoint(_layer, layer, h, lens, heads, cd, training, p_hidden, p_attn, eps, use_reentrant=False)
+            h = checkpoint(_layer, lw, h, lens, heads, training, p_hidden, p_attn, eps, use_reentrant=False)
         else:
-            h = _layer(layer, h, lens, heads, cd, training, p_hidden, p_attn, eps)
+            h = _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps)
     return h
 
 

@@ -75,6 +75,29 @@ __global__ void col_reduce_final_kernel(const float* __restrict__ partial, int c
   }
 }
 
+// out[c] = sum_r partial[r][c] for a small [nrows, width] fp32 matrix: block = 32 columns x 8 row lanes,
+// independent loads in flight, fixed-order LDS tree (deterministic).
+static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ partial, int nrows, int64_t width,
+                                                        float* __restrict__ out) {
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int64_t c = (int64_t)blockIdx.x * 32 + tx;
+  float acc = 0.f;
+  if (c < width) {
+    int r = ty;
+    for (; r + 24 < nrows; r += 32) {
+      const float a0 = partial[(int64_t)r * width + c], a1 = partial[(int64_t)(r + 8) * width + c];
+      const float a2 = partial[(int64_t)(r + 16) * width + c], a3 = partial[(int64_t)(r + 24) * width + c];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; r < nrows; r += 8) acc += partial[(int64_t)r * width + c];
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && c < width)
+    out[c] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+}
+
 // out: [K, f] (k-major).  Returns a gmlm status.
 template <int K, typename Fn>
 int col_reduce(int64_t n, int64_t f, Fn fn, float* out, void* workspace, size_t workspace_bytes, hipStream_t st,

@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restri
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t b = cdiv(rows, 8);  // >= 2 rows per wave
-  return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+  return (int)(b < 1 ? 1 : (b > 768 ? 768 : b));
 }
 
 }  // namespace gmlm

@@ -84,18 +84,20 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
   }
 }
 
+// dbias partials ride along: a thread owns V fixed columns, so it keeps their column sums in registers
+// over the rows it streams and writes one partial row per blockIdx.y (summed by rows_sum_kernel).
 template <typename T>
 __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ bias, int64_t rows, int64_t f,
                                                              uint32_t thresh, float keep_scale, uint64_t seed,
-                                                             T* __restrict__ dx) {
+                                                             T* __restrict__ dx, float* __restrict__ dbias_partial) {
   constexpr int V = Store<T>::kVec;
   const int64_t nch = f / V;
   const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (ch >= nch) return;
-  float bv[V];
+  float bv[V], acc[V];
 #pragma unroll
-  for (int v = 0; v < V; ++v) bv[v] = bias ? bias[ch * V + v] : 0.f;
+  for (int v = 0; v < V; ++v) { bv[v] = bias ? bias[ch * V + v] : 0.f; acc[v] = 0.f; }
   for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
     const int64_t off = r * f + ch * V;
     float a[V], g[V];
@@ -105,8 +107,13 @@ __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict_
     for (int v = 0; v < V; ++v) {
       if (thresh) g[v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
       g[v] *= gelu_erf_grad(a[v] + bv[v]);
+      acc[v] += g[v];
     }
     Store<T>::stv(dx + off, g);
+  }
+  if (dbias_partial) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) dbias_partial[(int64_t)blockIdx.y * f + ch * V + v] = acc[v];
   }
 }
 
@@ -209,23 +216,46 @@ extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows
   return GMLM_OK;
 }
 
+static inline dim3 bias_gelu_bwd_grid(int64_t rows, int64_t chunks) {
+  const int ct = (int)cdiv(chunks, 256);
+  int64_t ry = cdiv(1024, ct);
+  if (ry > rows) ry = rows;
+  if (ry < 1) ry = 1;
+  return dim3(ct, (unsigned)ry);
+}
+
+extern "C" size_t gmlm_bias_gelu_bwd_workspace_bytes(int64_t rows, int64_t f, int dtype) {
+  const dim3 g = bias_gelu_bwd_grid(rows, f / (dtype == GMLM_F32 ? 4 : 8));
+  return (size_t)g.y * f * sizeof(float);
+}
+
 extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
                                   uint64_t seed, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
                                   gmlm_stream_t stream) {
   int rc = bg_check("bias_gelu_bwd", rows, f, dtype, dropout_p);
   if (rc != GMLM_OK) return rc;
   hipStream_t st = as_stream(stream);
-  if (rows > 0) {
-    GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
-    const uint32_t th = dropout_threshold(dropout_p);
-    const float ks = 1.f / (1.f - dropout_p);
-    if (dtype == GMLM_F32)
-      bias_gelu_bwd_kernel<float><<<stream_grid(rows, f / 4), 256, 0, st>>>((const float*)dy, (const float*)x, bias, rows, f, th, ks, seed, (float*)dx);
-    else
-      bias_gelu_bwd_kernel<bf16_t><<<stream_grid(rows, f / 8), 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)dx);
+  if (rows == 0) {
+    if (dbias) GMLM_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * f, st));
+    return GMLM_OK;
+  }
+  GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
+  const uint32_t th = dropout_threshold(dropout_p);
+  const float ks = 1.f / (1.f - dropout_p);
+  const dim3 grid = bias_gelu_bwd_grid(rows, f / (dtype == GMLM_F32 ? 4 : 8));
+  float* partial = nullptr;
+  if (dbias) {
+    GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_bias_gelu_bwd_workspace_bytes(rows, f, dtype), "bias_gelu_bwd: workspace too small");
+    partial = static_cast<float*>(workspace);
+  }
+  if (dtype == GMLM_F32)
+    bias_gelu_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dy, (const float*)x, bias, rows, f, th, ks, seed, (float*)dx, partial);
+  else
+    bias_gelu_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)dx, partial);
+  GMLM_LAUNCH_CHECK();
+  if (dbias) {
+    rows_sum_kernel<<<(unsigned)cdiv(f, 32), 256, 0, st>>>(partial, (int)grid.y, f, dbias);
     GMLM_LAUNCH_CHECK();
   }
-  if (!dbias) return GMLM_OK;
-  if (dtype == GMLM_F32) return col_reduce<1>(rows, f, ColSumFn<float>{(const float*)dx, f}, dbias, workspace, workspace_bytes, st);
-  return col_reduce<1>(rows, f, ColSumFn<bf16_t>{(const bf16_t*)dx, f}, dbias, workspace, workspace_bytes, st);
+  return GMLM_OK;
 }

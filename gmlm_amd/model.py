@@ -188,13 +188,14 @@ class GraphTextLM(nn.Module):
         idx = idx[order.to(dev)]
         grad = self.plm_encoder.training or self.training
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
+            weights = bert.prepare_weights(self.plm_encoder, cd)          # cast / fuse once, share across micro-batches
             for s in range(0, a, plm_batch_size):
                 bi = idx[s:s + plm_batch_size]
                 lmax = max(int(lens_h[s:s + plm_batch_size].max()), 1)   # host-side: no sync
                 ids = tokens.input_ids[bi, :lmax]
                 lens = tokens.lens[bi]
                 hs = bert.bert_encode(self.plm_encoder, ids, lens, cd, self.plm_encoder.training,
-                                      self.plm_gradient_checkpointing)
+                                      self.plm_gradient_checkpointing, weights)
                 plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, lens, bi)
         return plm_embeds
 

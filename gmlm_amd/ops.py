@@ -385,6 +385,52 @@ class Attention(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+class AttentionQKV(torch.autograd.Function):
+    """Self-attention on a fused [b, l, 3*h*d] QKV buffer (BERT layout).  Forward reads q/k/v in place
+    through row strides; backward writes dq|dk|dv straight into ONE [b, l, 3*h*d] gradient buffer, so no
+    slice-gradient accumulation passes are needed."""
+
+    @staticmethod
+    def forward(ctx, qkv, kv_len, h, scale, p, seed):
+        _cuda(qkv)
+        qkv = qkv.contiguous()
+        b, l, hd3 = qkv.shape
+        hd = hd3 // 3
+        d = hd // h
+        q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
+        out = torch.empty(b, l, hd, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(b, h, l, dtype=torch.float32, device=qkv.device)
+        with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * l * l * d):
+            check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
+                                           float(p), seed, _ptr(out), _ptr(lse), _dt(qkv), _stream()), "gmlm_attention_fwd")
+        ctx.save_for_backward(qkv, out, lse, kv_len)
+        ctx.cfg = (h, float(scale), float(p), seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, out, lse, kv_len = ctx.saved_tensors
+        h, scale, p, seed = ctx.cfg
+        b, l, hd3 = qkv.shape
+        hd = hd3 // 3
+        d = hd // h
+        gout = gout.contiguous().to(qkv.dtype)
+        q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
+        dqkv = torch.empty_like(qkv)
+        dq, dk, dv = dqkv[..., :hd], dqkv[..., hd:2 * hd], dqkv[..., 2 * hd:]
+        ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, h, l, l, d), qkv.device)
+        with _span("attn_bwd_d%d" % d, flops=10.0 * b * h * l * l * d):
+            check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
+                                           l, l, d, hd3, hd3, hd3, scale, p, seed, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
+                                           hd3, _dt(qkv), _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
+        return dqkv, None, None, None, None, None
+
+
+def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False):
+    p = float(dropout_p) if training else 0.0
+    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0)
+
+
 def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
     p = float(dropout_p) if training else 0.0
     return Attention.apply(q, k, v, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0)
@@ -486,7 +532,7 @@ class BiasGelu(torch.autograd.Function):
         gy2 = gy.contiguous().view(rows, f).to(x2.dtype)
         dx = torch.empty_like(x2)
         dbias = torch.empty(f, dtype=torch.float32, device=x2.device) if has_bias else None
-        ws = _ws(lib().gmlm_colstats_workspace_bytes(rows, f), x2.device)
+        ws = _ws(lib().gmlm_bias_gelu_bwd_workspace_bytes(rows, f, _dt(x2)), x2.device)
         check(lib().gmlm_bias_gelu_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), rows, f, p, seed, _ptr(dx), _ptr(dbias), _dt(x2),
                                        _ptr(ws), ws.numel(), _stream()), "gmlm_bias_gelu_bwd")
         return dx.view(shape), dbias, None, None

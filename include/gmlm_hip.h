@@ -201,7 +201,9 @@ int gmlm_softmask_blend_bwd(const float* dout, int64_t dout_stride, const uint8_
  * (hf:modeling_bert.py:333-336) and classifier.1 (main.py:245): y = dropout(gelu(x + bias)). */
 int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed,
                        void* y, int dtype, gmlm_stream_t stream);
-/* dx = dy * dropout_mask * gelu'(x + bias); dbias (nullable) [f] = column sums (zeroed by the call). */
+/* dx = dy * dropout_mask * gelu'(x + bias); dbias (nullable) [f] = column sums of dx, accumulated in fp32
+ * inside the same pass (workspace: gmlm_bias_gelu_bwd_workspace_bytes). */
+size_t gmlm_bias_gelu_bwd_workspace_bytes(int64_t rows, int64_t f, int dtype);
 int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
                        uint64_t seed, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
                        gmlm_stream_t stream);
