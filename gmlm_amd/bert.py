@@ -59,9 +59,57 @@ def prepare_weights(plm, cd):
     return [LayerWeights(layer, cd) for layer in plm.encoder.layer]
 
 
+_F32_OUT = [True]          # torch.bmm(..., out_dtype=float32) available (checked on first use)
+
+
+def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
+    """dW [N, K] = dy2^T [N, T] @ x2 [T, K].  The reduction dim is the token count (10^4..10^5) while the
+    output is only a few 256x256 tiles, so one hipBLASLt call leaves most CUs idle; cutting T into S
+    slices (batched GEMM, fp32 partials) and adding them fills the chip (measured 1.5-2.7x on MI355X)."""
+    t, n = dy2.shape
+    k = x2.shape[1]
+    tiles = ((n + 255) // 256) * ((k + 255) // 256)
+    s = 1
+    if tiles < 128 and t >= 4096:
+        import math
+        s = min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
+        while s > 1 and t % s:
+            s //= 2
+    if s == 1:
+        return dy2.t() @ x2
+    a = dy2.view(s, t // s, n).transpose(1, 2)
+    b = x2.view(s, t // s, k)
+    if _F32_OUT[0] and dy2.dtype != torch.float32:
+        try:
+            return torch.bmm(a, b, out_dtype=torch.float32).sum(0).to(dy2.dtype)
+        except (RuntimeError, TypeError):
+            _F32_OUT[0] = False
+    return torch.bmm(a, b).float().sum(0).to(dy2.dtype)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ w^T (+ b) on hipBLASLt; backward uses the split-K weight gradient above."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        x2 = x.reshape(-1, x.shape[-1])
+        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = _splitk_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
+        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 def _mm(x, w, b=None):
     with torch.autocast("cuda", enabled=False):
-        return torch.nn.functional.linear(x, w, b)
+        return _Linear.apply(x, w, b)
 
 
 def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps):
