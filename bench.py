@@ -157,6 +157,17 @@ def micro(dev, args):
     import gmlm_amd
     from gmlm_amd import ops
     out = {}
+    groups = set(args.micro_select.split(","))
+    if "spmm" in groups:
+        _micro_spmm(dev, args, out)
+    if "attn" in groups:
+        _micro_attn(dev, args, out)
+    return out
+
+
+def _micro_spmm(dev, args, out):
+    import gmlm_amd
+    from gmlm_amd import ops
     g = torch.Generator(device=dev).manual_seed(5)
     n, e, f = args.micro_nodes, args.micro_edges, 768
     w = (torch.arange(n, device=dev, dtype=torch.float32) + 1.0).pow(-1.0 / 1.2)          # Chung-Lu, alpha = 2.2
@@ -183,6 +194,10 @@ def micro(dev, args):
         del x, gh, gx
     del csr, ei
     torch.cuda.empty_cache()
+
+
+def _micro_attn(dev, args, out):
+    from gmlm_amd import ops
     for tag, b, h, l, d, masked in (("mha_L512", 32, 12, 512, 64, True), ("mha_L128", 256, 12, 128, 64, True),
                                     ("xattn_N5201", 1, 8, 5201, 96, False), ("xattn_N20804", 1, 8, 20804, 96, False)):
         q, k, v = (torch.randn(b, l, h * d, device=dev, dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
@@ -198,7 +213,15 @@ def micro(dev, args):
                     "bwd_frac_mfma_peak": round(2.5 * fl / avg_b / 1e9 / MFMA_BF16_PEAK_TF, 4),
                     "note": "padded flops (masked keys counted)" if masked else "no mask"}
         del q, k, v, go, y
-    return out
+
+
+def _pmc_traffic(key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_spmm_traffic.json); None if absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_spmm_traffic.json")) as f:
+            return json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -218,8 +241,10 @@ def main():
     ap.add_argument("--cpu-plm-sample", type=int, default=16)
     ap.add_argument("--cpu-hc", type=int, default=768)
     ap.add_argument("--no-kernel-timers", action="store_true")
-    ap.add_argument("--micro", action="store_true", help="also run the kernel micro-benchmarks (rank 0, N=1)")
+    ap.add_argument("--no-micro", action="store_true", help="skip the kernel micro-benchmarks (rank 0, N=1 only)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = 1-GPU rehearsal of the N>1 path)")
     ap.add_argument("--micro-only", action="store_true")
+    ap.add_argument("--micro-select", default="spmm,attn", help="comma list of micro-benchmark groups: spmm, attn")
     ap.add_argument("--micro-nodes", type=int, default=1_250_000)
     ap.add_argument("--micro-edges", type=int, default=12_500_000)
     args = ap.parse_args()
@@ -232,12 +257,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)     # gloo rehearsal: several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     if args.micro_only:
         print(json.dumps({"micro": micro(dev, args)}))
@@ -324,10 +353,19 @@ def main():
                                "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                                "avg_launch_ms": round(s["ms"] / s["launches"], 4)}
         out["kernels"] = kern
-    if rank == 0 and world == 1 and args.micro:
+    if rank == 0 and world == 1 and not args.no_micro:
         del model
         torch.cuda.empty_cache()
-        out["micro"] = micro(dev, args)
+        out["micro"] = mi = micro(dev, args)
+        # the HBM roofline binds only when the feature matrix is far larger than the 256 MiB Infinity Cache
+        sp = mi.get("spmm_fwd_bf16")
+        if sp:
+            out["roofline_hbm_regime"] = {
+                "kernel": "seg_reduce_vec_kernel (RGCN mean aggregation, forward) on a %d-node / %d-edge power-law shard, F=768 bf16"
+                          % (sp["nodes"], sp["edges"]),
+                "bound": "hbm", "achieved": sp["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sp["frac_hbm_peak"],
+                "traffic": _pmc_traffic("spmm_fwd_bf16"), "algorithmic_bytes_per_launch": int(sp["algorithmic_GB"] * 1e9),
+                "avg_launch_ms": sp["avg_ms"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args, data, ids, am)

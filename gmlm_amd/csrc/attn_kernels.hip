@@ -201,6 +201,7 @@ __device__ __forceinline__ float drop_mul16(uint32_t word, int half, uint32_t th
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kDefer = 6.f;   // log2 units: skip the online-softmax rescale while the max grows by < 2^6
 constexpr float kLn2 = 0.6931471805599453f;
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
@@ -275,8 +276,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
         }
     }
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
-    const float m_new = fmaxf(m, rmax * sl2);       // finite: key kv0 is always valid
-    const float alpha = fast_exp2(m - m_new);       // m = -inf -> 0
+    // deferred rescale: keep the old reference max while the new one exceeds it by < 2^kDefer (probabilities
+    // then stay <= 2^kDefer, harmless in fp32 / bf16); the O and l rescale is skipped for the whole wave then
+    float m_new = fmaxf(m, rmax * sl2);             // finite: key kv0 is always valid
+    const bool keep = __all(m_new - m <= kDefer);   // m = -inf (first tile) -> false
+    float alpha = 1.f;
+    if (keep) m_new = m;
+    else alpha = fast_exp2(m - m_new);              // m = -inf -> 0
     float rsum = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -297,10 +303,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     rsum += __shfl_xor(rsum, 32, 64);
     l = l * alpha + rsum;
     m = m_new;
+    if (!keep) {
 #pragma unroll
-    for (int d = 0; d < DB; ++d)
+      for (int d = 0; d < DB; ++d)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+        for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) mma_acc<D>(vs[cur], PITCH, kb * 32, s[kb], o, lane);
     if (DBUF) {

@@ -403,3 +403,29 @@ def test_spmm_power_law_long_segments(dev):
     href.backward(go)
     np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-4, atol=1e-4)
     assert torch.equal(h, RGCNAggregate.apply(xg, csr))          # deterministic
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+def test_attention_online_softmax_rescale_branch(dev, dt, tol):
+    """The kernel skips the running-max rescale while the max grows by < 2^6 and rescales otherwise.  Random
+    data almost never takes the rescale branch after the first tile, so force it: a few keys far down the
+    sequence score 40+ above everything before them for some queries (and not for others)."""
+    from gmlm_amd.ops import attention
+    b, h, l, d = 1, 2, 400, 64
+    g = torch.Generator().manual_seed(17)
+    q, k, v = (torch.randn(b, l, h * d, generator=g) for _ in range(3))
+    k[0, 70] = q[0, 5] * 6.0          # tile 1: huge score for query 5 (and a few correlated ones)
+    k[0, 333] = q[0, 200] * 9.0       # tile 5: another jump for query 200
+    k[0, 399] = q[0, 5] * 12.0        # last (partial) tile: second jump for query 5
+    q, k, v = q.to(dt), k.to(dt), v.to(dt)
+    ref = _attn_ref(q.float(), k.float(), v.float(), None, h, d ** -0.5)
+    qd, kd, vd = (x.to(dev).requires_grad_(True) for x in (q, k, v))
+    y = attention(qd, kd, vd, None, h, d ** -0.5)
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
+    go = torch.randn(b, l, h * d, generator=g)
+    qr, kr, vr = (x.float().clone().requires_grad_(True) for x in (q, k, v))
+    _attn_ref(qr, kr, vr, None, h, d ** -0.5).backward(go)
+    y.backward(go.to(dev, dt))
+    for a, r_ in ((qd, qr), (kd, kr), (vd, vr)):
+        sc = float(r_.grad.abs().max())
+        np.testing.assert_allclose(a.grad.float().cpu().numpy(), r_.grad.numpy(), rtol=50 * tol, atol=2 * tol * sc)
