@@ -85,7 +85,8 @@ def _segment_sort(node, rel, remap, r_active, num_segments):
 
 def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
                   edge_type: Optional[torch.Tensor] = None, num_src: Optional[int] = None,
-                  src_degree_for_types: Optional[torch.Tensor] = None) -> RelCSR:
+                  src_degree_for_types: Optional[torch.Tensor] = None,
+                  active_relations: Optional[List[int]] = None) -> RelCSR:
     """edge_index int64 [2, E] with edge_index[0] = source (row of x), edge_index[1] = target in [0, num_nodes).
 
     ``num_src`` > num_nodes allows source ids that point at appended halo rows (multi-GPU partition).
@@ -115,6 +116,10 @@ def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
     if int(cnt_h.sum()) != e:
         raise ValueError(f"edge_type has values outside [0, {num_relations})")
     active = [r for r in range(num_relations) if int(cnt_h[r]) > 0] or [0]
+    if active_relations is not None:     # node partition: every rank must use the GLOBAL relation slots
+        if not set(active) <= set(active_relations) and int(cnt_h.sum()) > 0:
+            raise ValueError(f"local relations {active} are not a subset of the given relation slots {active_relations}")
+        active = sorted(int(r) for r in active_relations)
     remap_h = torch.full((num_relations,), -1, dtype=torch.int32)
     for slot, r in enumerate(active):
         remap_h[r] = slot

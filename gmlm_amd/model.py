@@ -115,7 +115,7 @@ class GraphTextLM(nn.Module):
         conv, norm, drop = getattr(self, f"rgcn{k}"), getattr(self, f"gnorm{k}"), getattr(self, f"dropout{k}")
         if self.dist is not None:
             x = self.dist.with_halo(x)                                # [n_local + n_halo, F]
-        z = conv.forward_csr(x, csr)                                  # fp32 [n, out]
+        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None)   # fp32 [n, out]
         cd = x.dtype
         n_total = self.dist.n_total if self.dist is not None else z.size(0)
         if n_total > 1:                                               # main.py:273 guard
