@@ -31,6 +31,9 @@ SIGNATURES = {
     "gmlm_segment_inv_count": (C.c_int, [_p, _i64, _p, _p]),
     "gmlm_rgcn_mean_spmm": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _i64,
                                       _p, _p]),
+    "gmlm_basis_compose_fwd": (C.c_int, [_p, _p, _i32, _i32, _i64, _p, _p]),
+    "gmlm_basis_compose_bwd_workspace_bytes": (_sz, [_i32, _i32, _i64]),
+    "gmlm_basis_compose_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_colstats_workspace_bytes": (_sz, [_i64, _i64]),
     "gmlm_colstats": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_graphnorm_finalize": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _p, _p, _p]),

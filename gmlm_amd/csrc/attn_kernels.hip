@@ -189,8 +189,8 @@ struct TileRegs {
 // attention-probability dropout: one 32-bit hash word decides TWO adjacent keys (16-bit thresholds), so the
 // per-element cost next to the MFMAs is ~1 integer multiply.  word = f(seed, (b,h,q), key >> 1); the
 // same function is evaluated by forward, dQ and dK/dV kernels (nothing is stored).
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {   // one multiply round: enough for a dropout mask
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
   return x;
 }
 __device__ __forceinline__ uint32_t drop_word(uint32_t seed, uint32_t qmix, uint32_t keypair) {

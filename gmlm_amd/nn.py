@@ -47,23 +47,46 @@ def _linear(x, weight, bias=None):
 
 
 class _BasisCompose(torch.autograd.Function):
-    """W_r = sum_b comp[r, b] * weight[b] for the relations that occur.  In the node-partitioned run the
-    gradient of the (R_a x in*out) composed weights is all-reduced BEFORE it is expanded to the 30 bases:
-    R_a/30 of the bytes of reducing d(weight) itself (the bases are 70 % of all parameters at hc = 768)."""
+    """W_r = sum_b comp[r, b] * weight[b] for the relations that occur (K10, one streaming pass over the
+    bases).  In the node-partitioned run the gradient of the (R_a x in*out) composed weights is all-reduced
+    BEFORE it is expanded to the 30 bases: R_a/30 of the bytes of reducing d(weight) itself (the bases are
+    70 % of all parameters at hc = 768)."""
 
     @staticmethod
     def forward(ctx, comp_a, weight2d, reducer):
+        comp_a, weight2d = comp_a.detach().float().contiguous(), weight2d.detach().float().contiguous()
+        ra, nb = comp_a.shape
+        cols = weight2d.shape[1]
         ctx.save_for_backward(comp_a, weight2d)
         ctx.reducer = reducer
-        return comp_a @ weight2d
+        if not weight2d.is_cuda or nb > 32 or ra > 5 or cols % 4:
+            if not weight2d.is_cuda:
+                raise ops._lib.GmlmHipError("gmlm_amd ops run on the GPU only; there is no CPU path")
+            ctx.hip = False
+            return comp_a @ weight2d                    # unusual geometry (> 32 bases / > 5 relations): hipBLASLt
+        ctx.hip = True
+        w = torch.empty(ra, cols, dtype=torch.float32, device=weight2d.device)
+        ops.check(ops.lib().gmlm_basis_compose_fwd(ops._ptr(comp_a), ops._ptr(weight2d), ra, nb, cols, ops._ptr(w),
+                                                   ops._stream()), "gmlm_basis_compose_fwd")
+        return w
 
     @staticmethod
     def backward(ctx, dw):
         comp_a, weight2d = ctx.saved_tensors
-        dw = dw.contiguous()
+        dw = dw.float().contiguous()
         if ctx.reducer is not None:
             ctx.reducer(dw)
-        return dw @ weight2d.t(), comp_a.t() @ dw, None
+        if not ctx.hip:
+            return dw @ weight2d.t(), comp_a.t() @ dw, None
+        ra, nb = comp_a.shape
+        cols = weight2d.shape[1]
+        dweight = torch.empty_like(weight2d)
+        dcomp = torch.empty_like(comp_a)
+        ws = ops._ws(ops.lib().gmlm_basis_compose_bwd_workspace_bytes(ra, nb, cols), dw.device)
+        ops.check(ops.lib().gmlm_basis_compose_bwd(ops._ptr(comp_a), ops._ptr(weight2d), ops._ptr(dw), ra, nb, cols,
+                                                   ops._ptr(dweight), ops._ptr(dcomp), ops._ptr(ws), ws.numel(), ops._stream()),
+                  "gmlm_basis_compose_bwd")
+        return dcomp, dweight, None
 
 
 class RGCNConv(nn.Module):

@@ -104,6 +104,20 @@ int gmlm_rgcn_mean_spmm(const void* src, int64_t src_rows, int64_t src_stride, c
                         float* partial, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K10  RGCN basis composition and its backward (PyG RGCNConv with num_bases; ctor sites main.py:189-203)
+ *   W[r, :] = sum_b comp[r, b] * weight[b, :]     comp [r_active, num_bases] (rows of the relations that occur),
+ *   weight [num_bases, cols = in*out], W [r_active, cols]; all fp32 (master parameters).
+ *   backward (one pass): dweight[b, :] = sum_r comp[r, b] * dW[r, :],  dcomp[r, b] = <dW[r, :], weight[b, :]>.
+ * r_active <= 5, num_bases <= 32, cols % 4 == 0.  Deterministic (fixed-order reductions).
+ * ------------------------------------------------------------------------------------------- */
+int gmlm_basis_compose_fwd(const float* comp, const float* weight, int r_active, int num_bases, int64_t cols,
+                           float* w, gmlm_stream_t stream);
+size_t gmlm_basis_compose_bwd_workspace_bytes(int r_active, int num_bases, int64_t cols);
+int gmlm_basis_compose_bwd(const float* comp, const float* weight, const float* dw, int r_active, int num_bases,
+                           int64_t cols, float* dweight, float* dcomp, void* workspace, size_t workspace_bytes,
+                           gmlm_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K4  GraphNorm (+ exact-erf GELU + dropout) forward / backward, single graph (batch = all rows)
  * replaces: torch_geometric.nn.GraphNorm.forward -> F.gelu -> nn.Dropout (main.py:273-275 ...)
  * ------------------------------------------------------------------------------------------- */

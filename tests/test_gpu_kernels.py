@@ -429,3 +429,20 @@ def test_attention_online_softmax_rescale_branch(dev, dt, tol):
     for a, r_ in ((qd, qr), (kd, kr), (vd, vr)):
         sc = float(r_.grad.abs().max())
         np.testing.assert_allclose(a.grad.float().cpu().numpy(), r_.grad.numpy(), rtol=50 * tol, atol=2 * tol * sc)
+
+
+@pytest.mark.parametrize("ra,nb,cols", [(1, 30, 768 * 1536), (4, 30, 64 * 128), (5, 32, 1000), (3, 7, 2096 * 16)])
+def test_basis_compose_fwd_bwd(dev, ra, nb, cols):
+    """K10: W_r = sum_b comp[r,b] weight[b] and the fused backward (dweight, dcomp) vs autograd."""
+    from gmlm_amd.nn import _BasisCompose
+    g = torch.Generator().manual_seed(ra * 100 + nb)
+    comp, weight, gw = torch.randn(ra, nb, generator=g), torch.randn(nb, cols, generator=g), torch.randn(ra, cols, generator=g)
+    cr, wr = comp.clone().requires_grad_(True), weight.clone().requires_grad_(True)
+    (cr @ wr).backward(gw)
+    cd_, wd = comp.to(dev).requires_grad_(True), weight.to(dev).requires_grad_(True)
+    w = _BasisCompose.apply(cd_, wd, None)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), (comp @ weight).numpy(), rtol=1e-5, atol=1e-5)
+    w.backward(gw.to(dev))
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-5, atol=1e-5)
+    sc = float(cr.grad.abs().max())
+    np.testing.assert_allclose(cd_.grad.cpu().numpy(), cr.grad.numpy(), rtol=1e-4, atol=1e-5 * sc)
