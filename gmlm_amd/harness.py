@@ -1,0 +1,154 @@
+"""Training / evaluation step around the hot path — the thin counterpart of ``train_model`` /
+``evaluate_model`` (main.py:488-720) that turns the kernel path into an end-to-end step.
+
+Only the step logic is mirrored (mask sampling -> soft mask -> forward -> CE(label_smoothing=0.2) ->
+backward -> clip_grad_norm_(1.0) -> AdamW(3 name-based groups) -> linear warm-up), with stock
+``torch.optim`` / schedulers exactly like the reference; logging, wandb, early stopping bookkeeping and the
+experiment driver stay with the caller.
+"""
+from __future__ import annotations
+
+import random
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import ops
+
+GNN_PARAM_NAMES = ['rgcn1', 'rgcn2', 'rgcn3', 'gnorm1', 'gnorm2', 'gnorm3', 'residual_proj1', 'residual_proj2',
+                   'residual_proj3']   # main.py:379 (rgcn4 / gnorm4 fall into "other", as in the reference)
+
+
+def setup_optimizer(model, lr_graph, lr_bert, lr_other, weight_decay):
+    """main.py:375-398: AdamW with three parameter groups selected by NAME."""
+    graph_params, bert_params, other_params = [], [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if name.startswith('plm_encoder.'):
+            bert_params.append(param)
+        elif any(g in name for g in GNN_PARAM_NAMES):
+            graph_params.append(param)
+        else:
+            other_params.append(param)
+    return optim.AdamW([
+        {'params': graph_params, 'lr': lr_graph, 'weight_decay': weight_decay},
+        {'params': bert_params, 'lr': lr_bert, 'weight_decay': 0.01},
+        {'params': other_params, 'lr': lr_other, 'weight_decay': weight_decay}])
+
+
+def linear_warmup_schedule(optimizer, num_warmup_steps, num_training_steps):
+    """``transformers.get_linear_schedule_with_warmup`` (main.py:504) as a plain LambdaLR."""
+    def lr_lambda(step):
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        return max(0.0, float(num_training_steps - step) / float(max(1, num_training_steps - num_warmup_steps)))
+    return optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+
+
+def generate_active_node_mask(x, edge_index, mask_ratio, base_mask: Optional[torch.Tensor] = None):
+    """main.py:47-89 on the device: base nodes -> degree-proportional sampling without replacement.
+    The degree histogram is the K1 kernel (bit-exact); the sampling itself is torch's RNG, as in the
+    reference (not reproducible across devices, so parity tests pass masks in as inputs)."""
+    n = x.size(0)
+    dev = x.device
+    base = base_mask.nonzero(as_tuple=False).reshape(-1) if base_mask is not None else torch.arange(n, device=dev)
+    nb = base.numel()
+    out = torch.zeros(n, dtype=torch.bool, device=dev)
+    if nb == 0:
+        return out
+    num_select = max(1, min(int(mask_ratio * nb), nb))
+    deg = ops.degree(edge_index[0].to(torch.long), n)[base]
+    tot = deg.sum()
+    if float(tot) == 0:
+        sel = base[torch.randperm(nb, device=dev)[:num_select]]
+    else:
+        probs = torch.nan_to_num(deg / tot, nan=1.0 / nb)
+        sel = base[torch.multinomial(probs, num_select, replacement=False)]
+    out[sel] = True
+    return out
+
+
+@dataclass
+class StepResult:
+    loss: float
+    accuracy: float
+    skipped: bool = False
+
+
+def train_step(model, optimizer, scheduler, x, edge_index, texts, y, active_mask, *, beta=0.7, plm_batch_size=32,
+               grad_clip_norm=1.0, autocast: bool = True, label_smoothing=0.2) -> StepResult:
+    """One iteration of the epoch loop main.py:528-563 (full-batch: one forward + backward per epoch)."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    if not bool(active_mask.any()):
+        return StepResult(float('nan'), 0.0, True)
+    with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        xm = model.soft_mask_input(x, active_mask, beta)
+        logits = model(xm, edge_index, texts, active_mask, edge_type=None, plm_batch_size=plm_batch_size)
+        loss = F.cross_entropy(logits[active_mask], y[active_mask], label_smoothing=label_smoothing)
+    with torch.no_grad():
+        acc = float((logits[active_mask].argmax(1) == y[active_mask]).float().mean())
+    if not bool(torch.isfinite(loss)):
+        return StepResult(float(loss), acc, True)
+    loss.backward()
+    if model.dist is not None:
+        model.dist.all_reduce_grads(model)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=grad_clip_norm)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return StepResult(float(loss.detach()), acc)
+
+
+@torch.no_grad()
+def eval_step(model, x, edge_index, texts, y, mask, *, plm_batch_size=32, autocast: bool = True):
+    """main.py:584-616 / 669-720: eval forward on ``mask`` -> (loss, accuracy, macro-F1)."""
+    model.eval()
+    with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        logits = model(x, edge_index, texts, mask, edge_type=None, plm_batch_size=plm_batch_size)
+    lg, lab = logits[mask], y[mask]
+    if lab.numel() == 0:
+        return float('nan'), 0.0, 0.0
+    loss = float(F.cross_entropy(lg, lab))
+    pred = lg.argmax(1)
+    acc = float((pred == lab).float().mean())
+    c = int(max(int(lab.max()), int(pred.max()))) + 1
+    f1s = []
+    for k in range(c):
+        tp = float(((pred == k) & (lab == k)).sum())
+        fp = float(((pred == k) & (lab != k)).sum())
+        fn = float(((pred != k) & (lab == k)).sum())
+        if tp + fp + fn > 0:
+            f1s.append(2 * tp / (2 * tp + fp + fn))
+    return loss, acc, float(sum(f1s) / max(len(f1s), 1))
+
+
+def train_model(model, x, edge_index, texts, y, train_mask, val_mask=None, *, num_epochs=500,
+                active_node_mask_ratio_min=0.2, active_node_mask_ratio_max=0.4, beta_soft_mask_gnn=0.7, lr_graph=1e-3,
+                lr_bert=1e-5, lr_other=1e-4, weight_decay=0.01, patience=20, warmup_ratio=0.1, grad_clip_norm=1.0,
+                plm_batch_size=32, autocast=True, on_epoch=None):
+    """Epoch loop with the reference's hyper-parameter names (main.py:488-493); returns the loss list."""
+    optimizer = setup_optimizer(model, lr_graph, lr_bert, lr_other, weight_decay)
+    scheduler = linear_warmup_schedule(optimizer, int(num_epochs * warmup_ratio), num_epochs)
+    losses, best_f1, bad = [], 0.0, 0
+    for epoch in range(num_epochs):
+        ratio = random.uniform(active_node_mask_ratio_min, active_node_mask_ratio_max)
+        mask = generate_active_node_mask(x, edge_index, ratio, train_mask)
+        res = train_step(model, optimizer, scheduler, x, edge_index, texts, y, mask, beta=beta_soft_mask_gnn,
+                         plm_batch_size=plm_batch_size, grad_clip_norm=grad_clip_norm, autocast=autocast)
+        losses.append(res.loss)
+        if val_mask is not None and bool(val_mask.any()) and (epoch % 5 == 0 or epoch == num_epochs - 1):
+            _, _, f1 = eval_step(model, x, edge_index, texts, y, val_mask, plm_batch_size=plm_batch_size, autocast=autocast)
+            if f1 > best_f1:
+                best_f1, bad = f1, 0
+            else:
+                bad += 1
+            if bad >= patience:
+                break
+        if on_epoch is not None:
+            on_epoch(epoch, res)
+    return losses

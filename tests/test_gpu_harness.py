@@ -1,0 +1,75 @@
+"""Training-step harness (gmlm_amd.harness; counterpart of main.py:528-563) vs the same loop on the CPU
+oracle: three optimiser steps in fp32, dropout 0, masks captured as inputs -> same loss trajectory."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gmlm_oracle as O
+from helpers import oracle_model_from_config
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_training_steps_match_oracle():
+    import gmlm_amd
+    from gmlm_amd import harness
+    from test_gpu_model import build_model
+    dev = torch.device("cuda:0")
+    plm = dict(hidden=128, layers=2, heads=2, inter=256, max_pos=64, vocab=200)
+    n, e = 150, 700
+    cfg = dict(n=n, e=e, f_in=48, hc=32, c=4, plm=plm, seed=31)
+    g = torch.Generator().manual_seed(8)
+    x, ei = torch.randn(n, 48, generator=g), torch.randint(0, n, (2, e), generator=g)
+    y = torch.randint(0, 4, (n,), generator=g)
+    masks = [torch.rand(n, generator=g) < 0.4 for _ in range(3)]
+    ids, am = O.synthetic_tokens(n, 12, 200, 3, 2)
+    lrs = dict(lr_graph=1e-3, lr_bert=1e-4, lr_other=5e-4, weight_decay=0.01)
+
+    om, _ = oracle_model_from_config(cfg)
+    # the oracle registers PLM weights under plm_params.*: build the same three groups by hand
+    groups = [[], [], []]
+    for name, p in om.named_parameters():
+        if name.startswith("plm_params."):
+            groups[1].append(p)
+        elif any(s in name for s in harness.GNN_PARAM_NAMES):
+            groups[0].append(p)
+        else:
+            groups[2].append(p)
+    oopt = torch.optim.AdamW([{"params": groups[0], "lr": 1e-3, "weight_decay": 0.01},
+                              {"params": groups[1], "lr": 1e-4, "weight_decay": 0.01},
+                              {"params": groups[2], "lr": 5e-4, "weight_decay": 0.01}])
+    osched = harness.linear_warmup_schedule(oopt, 1, 10)
+    ref_losses = []
+    for mk in masks:
+        oopt.zero_grad()
+        xm = O.soft_masking_gnn_input(x, mk, om.gnn_mask_token_embed, 0.7)
+        loss = F.cross_entropy(om(xm, ei, ids, am, mk, plm_batch_size=64)[mk], y[mk], label_smoothing=0.2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(om.parameters(), 1.0)
+        oopt.step(); osched.step()
+        ref_losses.append(float(loss))
+
+    m = build_model(cfg, dev)
+    opt = harness.setup_optimizer(m, **lrs)
+    assert [len(gp["params"]) for gp in opt.param_groups] == [len(gr) for gr in groups]
+    sched = harness.linear_warmup_schedule(opt, 1, 10)
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    losses = []
+    for mk in masks:
+        r = harness.train_step(m, opt, sched, x.to(dev), ei.to(dev), tokens, y.to(dev), mk.to(dev), beta=0.7,
+                               plm_batch_size=64, autocast=False)
+        assert not r.skipped
+        losses.append(r.loss)
+    # step 1 is a pure forward comparison (1e-4); later steps also carry AdamW's sign-sensitive first updates
+    assert abs(losses[0] - ref_losses[0]) < 1e-4, (losses, ref_losses)
+    np.testing.assert_allclose(losses, ref_losses, rtol=0, atol=2e-3)
+    assert losses[2] < losses[0]
+    loss, acc, f1 = harness.eval_step(m, x.to(dev), ei.to(dev), tokens, y.to(dev), masks[0].to(dev), plm_batch_size=64,
+                                      autocast=False)
+    assert np.isfinite(loss) and 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
+    # degree-proportional mask sampling: right count, only base nodes
+    base = torch.zeros(n, dtype=torch.bool, device=dev)
+    base[:60] = True
+    mk = harness.generate_active_node_mask(x.to(dev), ei.to(dev), 0.5, base)
+    assert int(mk.sum()) == 30 and not bool(mk[60:].any())
