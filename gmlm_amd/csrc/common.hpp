@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
+#include <math.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -108,23 +109,26 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- replayable dropout mask: counter hash of (seed, element index) ---------------------------
-// splitmix64-style finaliser; the same (seed, idx) gives the same decision in forward, in the
+// 32-bit "lowbias" finaliser over (seed, idx >> 1): one hash word decides TWO adjacent elements with
+// 16-bit thresholds (P(drop) = th / 65536), so vector kernels pay ~1.5 integer multiplies per element
+// instead of three 64-bit ones.  The same (seed, idx) gives the same decision in forward, in the
 // checkpoint recompute and in backward, so no mask tensor is stored.
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-  uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (uint32_t)((z ^ (z >> 31)) >> 32);
+  uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u + (uint32_t)seed;
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x ^ (uint32_t)(seed >> 32);
 }
 // returns the multiplier applied to a kept / dropped element
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh, float keep_scale) {
-  return hash_u32(seed, idx) >= thresh ? keep_scale : 0.f;
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint32_t thresh16, float keep_scale) {
+  const uint32_t w = hash_u32(seed, idx >> 1);
+  return ((w >> (16 * (uint32_t)(idx & 1))) & 0xFFFFu) >= thresh16 ? keep_scale : 0.f;
 }
 inline uint32_t dropout_threshold(float p) {
   if (p <= 0.f) return 0u;
-  double t = (double)p * 4294967296.0;
-  return t >= 4294967295.0 ? 4294967295u : (uint32_t)t;
+  long t = lroundf(p * 65536.f);
+  return (uint32_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
 }
+inline float dropout_keep_scale(uint32_t thresh16) { return 65536.f / (65536.f - (float)thresh16); }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -110,9 +110,10 @@ __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, row cached in registers (CH chunks of 16 B per lane, CH <= 4).
-// gamma / beta / bias are the same for every row a lane touches (its columns are fixed), so they
-// are loaded once per wave with 16-byte loads and kept in registers.
+// LayerNorm: LPR lanes (32 or 64) per row, row cached in registers (CH chunks of 16 B per lane, CH <= 4);
+// with LPR = 32 a wave normalises two rows at once (f = 768 bf16 = 96 chunks = 32 lanes x 3: no idle lane).
+// gamma / beta / bias are the same for every row a lane touches (its columns are fixed), so they are
+// loaded once per wave with 16-byte loads and kept in registers.
 // ------------------------------------------------------------------------------------------------
 constexpr int kLnMaxCh = 4;
 
@@ -130,19 +131,26 @@ __device__ __forceinline__ void load_param(const float* __restrict__ p, int col,
   }
 }
 
-template <typename T, int CH, bool ACT>
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T, int CH, int LPR, bool ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                       const T* __restrict__ res, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int64_t rows, int f, float eps,
                                                       uint32_t thresh, float keep_scale, uint64_t seed, T* __restrict__ y,
                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o) {
-  constexpr int V = Store<T>::kVec;
-  const int lane = threadIdx.x & 63;
+  constexpr int V = Store<T>::kVec, RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR;
   const int nch = f / V;
   float gm[CH][V], bt[CH][V], bi[CH][V];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    const int ch = c * 64 + lane;
+    const int ch = c * LPR + lr;
     if (ch < nch) {
       load_param<V>(gamma, ch * V, gm[c], 1.f);
       load_param<V>(beta, ch * V, bt[c], 0.f);
@@ -152,13 +160,15 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const float inv_f = 1.f / (float)f;
-  for (int64_t r = wave0; r < rows; r += nwaves) {
+  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
     float z[CH][V];
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = c * 64 + lane;
-      if (ch < nch) {
+      const int ch = c * LPR + lr;
+      if (ch < nch && live) {
         const int64_t off = r * f + (int64_t)ch * V;
         Store<T>::ldv(x + off, z[c]);
         float rr[V];
@@ -172,25 +182,25 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         }
       }
     }
-    const float mu = wave_sum(sum) * inv_f;
+    const float mu = group_sum<LPR>(sum) * inv_f;
     float sq = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c)
-      if (c * 64 + lane < nch)
+      if (c * LPR + lr < nch && live)
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const float d = z[c][v] - mu;
           sq += d * d;
         }
-    const float rs = 1.f / sqrtf(wave_sum(sq) * inv_f + eps);
-    if (lane == 0) {
+    const float rs = 1.f / sqrtf(group_sum<LPR>(sq) * inv_f + eps);
+    if (lr == 0 && live) {
       if (mean_o) mean_o[r] = mu;
       if (rstd_o) rstd_o[r] = rs;
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = c * 64 + lane;
-      if (ch < nch) {
+      const int ch = c * LPR + lr;
+      if (ch < nch && live) {
         float o[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -203,42 +213,46 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
   }
 }
 
-// backward: each wave keeps per-lane partial dgamma/dbeta/dbias for its fixed columns and writes
-// partial[wave][3][f]; a second kernel sums the waves in a fixed tree order (deterministic).
-template <typename T, int CH, bool ACT>
+// backward: each lane keeps partial dgamma/dbeta/dbias for its fixed columns; the 4 waves (x 64/LPR row
+// groups) of a block are summed through LDS in a fixed order and the block writes ONE partial row
+// [3][f]; a second kernel sums the blocks in a fixed tree order (deterministic).
+template <typename T, int CH, int LPR, bool ACT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ bias, const T* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
                                                       int64_t rows, int f, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial) {
-  constexpr int V = Store<T>::kVec;
-  const int lane = threadIdx.x & 63;
+  constexpr int V = Store<T>::kVec, RPW = 64 / LPR;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3 * f]
+  const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR, wv = threadIdx.x >> 6;
   const int nch = f / V;
   float gm[CH][V], bt[CH][V], bi[CH][V];
   float dg[CH][V], db[CH][V], dbi[CH][V];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    const int ch = c * 64 + lane;
+    const int ch = c * LPR + lr;
     if (ch < nch) {
       load_param<V>(gamma, ch * V, gm[c], 1.f);
-      load_param<V>(beta, ch * V, bt[c], 0.f);
+      if (ACT) load_param<V>(beta, ch * V, bt[c], 0.f);
       load_param<V>(bias, ch * V, bi[c], 0.f);
     }
 #pragma unroll
     for (int v = 0; v < V; ++v) dg[c][v] = db[c][v] = dbi[c][v] = 0.f;
   }
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const float inv_f = 1.f / (float)f;
-  for (int64_t r = wave0; r < rows; r += nwaves) {
-    const float mu = mean[r], rs = rstd[r];
+  for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    const float mu = live ? mean[r] : 0.f, rs = live ? rstd[r] : 0.f;
     float zh[CH][V], dzh[CH][V];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = c * 64 + lane;
-      if (ch < nch) {
+      const int ch = c * LPR + lr;
+      if (ch < nch && live) {
         const int64_t off = r * f + (int64_t)ch * V;
         float gv[V], rr[V];
         Store<T>::ldv(x + off, zh[c]);
@@ -261,12 +275,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         }
       }
     }
-    s1 = wave_sum(s1) * inv_f;
-    s2 = wave_sum(s2) * inv_f;
+    s1 = group_sum<LPR>(s1) * inv_f;
+    s2 = group_sum<LPR>(s2) * inv_f;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
-      const int ch = c * 64 + lane;
-      if (ch < nch) {
+      const int ch = c * LPR + lr;
+      if (ch < nch && live) {
         const int64_t off = r * f + (int64_t)ch * V;
         float dz[V], dxv[V];
 #pragma unroll
@@ -280,21 +294,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  float* prow = partial + wave0 * 3 * (int64_t)f;
+  // block reduction: the two row groups of a wave (LPR = 32) first add up by shuffle, then the 4 waves
+  // through LDS (slot = wave), column-wise in a fixed order
+  float* mine = lds + (size_t)wv * 3 * f;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
-    const int ch = c * 64 + lane;
-    if (ch < nch) {
-      *reinterpret_cast<float4*>(prow + ch * V) = make_float4(dg[c][0], dg[c][1], dg[c][2], dg[c][3]);
-      *reinterpret_cast<float4*>(prow + f + ch * V) = make_float4(db[c][0], db[c][1], db[c][2], db[c][3]);
-      *reinterpret_cast<float4*>(prow + 2 * f + ch * V) = make_float4(dbi[c][0], dbi[c][1], dbi[c][2], dbi[c][3]);
-      if constexpr (V == 8) {
-        *reinterpret_cast<float4*>(prow + ch * V + 4) = make_float4(dg[c][4], dg[c][5], dg[c][6], dg[c][7]);
-        *reinterpret_cast<float4*>(prow + f + ch * V + 4) = make_float4(db[c][4], db[c][5], db[c][6], db[c][7]);
-        *reinterpret_cast<float4*>(prow + 2 * f + ch * V + 4) = make_float4(dbi[c][4], dbi[c][5], dbi[c][6], dbi[c][7]);
+    const int ch = c * LPR + lr;
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      float a = dg[c][v], b2 = db[c][v], c2 = dbi[c][v];
+      if (RPW == 2) {
+        a += __shfl_xor(a, 32, 64);
+        b2 += __shfl_xor(b2, 32, 64);
+        c2 += __shfl_xor(c2, 32, 64);
+      }
+      if (ch < nch && sub == 0) {
+        mine[ch * V + v] = a;
+        mine[f + ch * V + v] = b2;
+        mine[2 * f + ch * V + v] = c2;
       }
     }
   }
+  __syncthreads();
+  float* prow = partial + (int64_t)blockIdx.x * 3 * f;
+  for (int i = threadIdx.x; i < 3 * f; i += 256)
+    prow[i] = (lds[i] + lds[(size_t)3 * f + i]) + (lds[(size_t)6 * f + i] + lds[(size_t)9 * f + i]);
 }
 
 // out[c] = sum over `nrows` partial rows of partial[row][c], c in [0, 3f): block = 32 columns x 8 row lanes,
@@ -323,6 +347,17 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restri
     float* out = c < f ? dgamma : (c < 2 * f ? dbeta : dbias);
     if (out) out[c % f] = s;
   }
+}
+
+struct LnGeom { int lpr, ch; };
+// lanes per row: 32 when that leaves fewer idle lanes (e.g. 96 chunks = 32 x 3), else 64
+static inline LnGeom ln_geom(int64_t f, int dtype) {
+  const int nch = (int)(f / (dtype == GMLM_F32 ? 4 : 8));
+  const int idle32 = (int)cdiv(nch, 32) * 32 - nch, idle64 = (int)cdiv(nch, 64) * 64 - nch;
+  LnGeom g;
+  g.lpr = (nch <= 96 && idle32 < idle64) ? 32 : 64;
+  g.ch = (int)cdiv(nch, g.lpr);
+  return g;
 }
 
 static inline int ln_bwd_blocks(int64_t rows) {
@@ -370,7 +405,7 @@ extern "C" int gmlm_graphnorm_apply(const float* x, const float* mean, const flo
   if (n == 0) return GMLM_OK;
   GMLM_REQUIRE(x && mean && rstd && weight && bias && mean_scale && y, "graphnorm_apply: null pointer");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   const dim3 grid = col_stream_grid(n, f);
   hipStream_t st = as_stream(stream);
 #define L(TY, A) graphnorm_apply_kernel<TY, A><<<grid, 256, 0, st>>>(x, mean, rstd, weight, bias, mean_scale, n, f, th, ks, seed, (TY*)y)
@@ -389,7 +424,7 @@ extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const float* x
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_bwd_stats: unsupported dtype");
   GMLM_REQUIRE(n == 0 || (g && x && mean && rstd && weight && bias && mean_scale), "graphnorm_bwd_stats: null pointer");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   hipStream_t st = as_stream(stream);
 #define L(TG, A) return col_reduce<2>(n, f, GraphNormBwdStatsFn<TG, A>{(const TG*)g, x, mean, rstd, weight, bias, mean_scale, f, th, ks, seed}, gs, workspace, workspace_bytes, st)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
@@ -405,7 +440,7 @@ extern "C" int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const float* x
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_bwd_apply: unsupported dtype");
   GMLM_REQUIRE(mean && rstd && weight && bias && mean_scale && (n == 0 || (g && x && dx)), "graphnorm_bwd_apply: null pointer");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   dim3 grid = col_stream_grid(n > 0 ? n : 1, f);
   hipStream_t st = as_stream(stream);
 #define L(TG, A) graphnorm_bwd_apply_kernel<TG, A><<<grid, 256, 0, st>>>((const TG*)g, x, mean, rstd, weight, bias, mean_scale, gs, n, n_total, f, th, ks, seed, dx, dweight, dbias, dmean_scale)
@@ -420,8 +455,8 @@ static int ln_check(const char* who, int64_t rows, int64_t f, int dtype, float d
   GMLM_REQUIRE(rows >= 0 && f > 0, "%s: bad sizes", who);
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "%s: unsupported dtype", who);
   const int v = dtype == GMLM_F32 ? 4 : 8;
-  GMLM_REQUIRE(f % v == 0 && f <= 64 * v * kLnMaxCh, "%s: row width %ld must be a multiple of %d and <= %d", who, (long)f, v,
-               64 * v * kLnMaxCh);
+  GMLM_REQUIRE(f % v == 0 && f <= 64 * v * kLnMaxCh && f <= 1024, "%s: row width %ld must be a multiple of %d and <= %d", who,
+               (long)f, v, 64 * v * kLnMaxCh < 1024 ? 64 * v * kLnMaxCh : 1024);
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "%s: dropout_p must be in [0,1)", who);
   return GMLM_OK;
 }
@@ -436,12 +471,13 @@ extern "C" int gmlm_bias_res_layernorm_fwd(const void* x, const float* bias, con
   GMLM_REQUIRE(x && gamma && beta && y, "bias_res_layernorm_fwd: null pointer");
   GMLM_REQUIRE(aligned16(x) && aligned16(y) && (!residual || aligned16(residual)), "bias_res_layernorm_fwd: 16-byte alignment required");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
-  const int grid = grid_cap(cdiv(rows, 4));
+  const float ks = dropout_keep_scale(th);
   hipStream_t st = as_stream(stream);
-  const int ch = (int)cdiv(f / (dtype == GMLM_F32 ? 4 : 8), 64);
-#define L2(T, C, A) ln_fwd_kernel<T, C, A><<<grid, 256, 0, st>>>((const T*)x, bias, (const T*)residual, gamma, beta, rows, (int)f, eps, th, ks, seed, (T*)y, mean, rstd)
-#define L(T, A) do { if (ch <= 1) L2(T, 1, A); else if (ch == 2) L2(T, 2, A); else L2(T, 4, A); } while (0)
+  const LnGeom ge = ln_geom(f, dtype);
+  const int grid = grid_cap(cdiv(rows, 4 * (64 / ge.lpr)));
+#define L2(T, C, P, A) ln_fwd_kernel<T, C, P, A><<<grid, 256, 0, st>>>((const T*)x, bias, (const T*)residual, gamma, beta, rows, (int)f, eps, th, ks, seed, (T*)y, mean, rstd)
+#define L(T, A) do { if (ge.lpr == 32) { if (ge.ch <= 1) L2(T, 1, 32, A); else if (ge.ch == 2) L2(T, 2, 32, A); else L2(T, 3, 32, A); } \
+                     else { if (ge.ch <= 1) L2(T, 1, 64, A); else if (ge.ch == 2) L2(T, 2, 64, A); else if (ge.ch == 3) L2(T, 3, 64, A); else L2(T, 4, 64, A); } } while (0)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
@@ -451,7 +487,7 @@ extern "C" int gmlm_bias_res_layernorm_fwd(const void* x, const float* bias, con
 }
 
 extern "C" size_t gmlm_layernorm_bwd_workspace_bytes(int64_t rows, int64_t f) {
-  return (size_t)ln_bwd_blocks(rows) * 4 * 3 * f * sizeof(float);
+  return (size_t)ln_bwd_blocks(rows) * 3 * f * sizeof(float);
 }
 
 extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias, const void* residual,
@@ -471,18 +507,20 @@ extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const 
   GMLM_REQUIRE(dy && x && gamma && beta && mean && rstd && dx, "bias_res_layernorm_bwd: null pointer");
   GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_layernorm_bwd_workspace_bytes(rows, f), "bias_res_layernorm_bwd: workspace too small");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   const int blocks = ln_bwd_blocks(rows);
   float* partial = static_cast<float*>(workspace);
-  const int ch = (int)cdiv(f / (dtype == GMLM_F32 ? 4 : 8), 64);
-#define L2(T, C, A) ln_bwd_kernel<T, C, A><<<blocks, 256, 0, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
-#define L(T, A) do { if (ch <= 1) L2(T, 1, A); else if (ch == 2) L2(T, 2, A); else L2(T, 4, A); } while (0)
+  const LnGeom ge = ln_geom(f, dtype);
+  const size_t lds = (size_t)4 * 3 * f * sizeof(float);
+#define L2(T, C, P, A) ln_bwd_kernel<T, C, P, A><<<blocks, 256, lds, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
+#define L(T, A) do { if (ge.lpr == 32) { if (ge.ch <= 1) L2(T, 1, 32, A); else if (ge.ch == 2) L2(T, 2, 32, A); else L2(T, 3, 32, A); } \
+                     else { if (ge.ch <= 1) L2(T, 1, 64, A); else if (ge.ch == 2) L2(T, 2, 64, A); else if (ge.ch == 3) L2(T, 3, 64, A); else L2(T, 4, 64, A); } } while (0)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
 #undef L2
   GMLM_LAUNCH_CHECK();
-  ln_bwd_final_kernel<<<(int)cdiv(3 * f, 32), 256, 0, st>>>(partial, blocks * 4, (int)f, dgamma, dbeta, dbias);
+  ln_bwd_final_kernel<<<(int)cdiv(3 * f, 32), 256, 0, st>>>(partial, blocks, (int)f, dgamma, dbeta, dbias);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }

@@ -207,7 +207,7 @@ extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows
   if (rows == 0) return GMLM_OK;
   GMLM_REQUIRE(x && y && aligned16(x) && aligned16(y), "bias_gelu_fwd: null or misaligned pointer");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   if (dtype == GMLM_F32)
     bias_gelu_fwd_kernel<float><<<stream_grid(rows, f / 4), 256, 0, as_stream(stream)>>>((const float*)x, bias, rows, f, th, ks, seed, (float*)y);
   else
@@ -241,7 +241,7 @@ extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bi
   }
   GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
   const uint32_t th = dropout_threshold(dropout_p);
-  const float ks = 1.f / (1.f - dropout_p);
+  const float ks = dropout_keep_scale(th);
   const dim3 grid = bias_gelu_bwd_grid(rows, f / (dtype == GMLM_F32 ? 4 : 8));
   float* partial = nullptr;
   if (dbias) {
