@@ -351,11 +351,14 @@ __global__ __launch_bounds__(256) void ln_bwd_final_kernel(const float* __restri
 
 struct LnGeom { int lpr, ch; };
 // lanes per row: 32 when that leaves fewer idle lanes (e.g. 96 chunks = 32 x 3), else 64
-static inline LnGeom ln_geom(int64_t f, int dtype) {
+static inline LnGeom ln_geom(int64_t f, int dtype, bool backward = false) {
   const int nch = (int)(f / (dtype == GMLM_F32 ? 4 : 8));
   const int idle32 = (int)cdiv(nch, 32) * 32 - nch, idle64 = (int)cdiv(nch, 64) * 64 - nch;
   LnGeom g;
   g.lpr = (nch <= 96 && idle32 < idle64) ? 32 : 64;
+  // the backward kernel carries 3 accumulator sets per chunk: 3 chunks of 8 bf16 per lane need all 256 VGPRs
+  // (1 wave/SIMD); 64 lanes x 2 chunks with some idle lanes keeps 2 waves/SIMD and is faster
+  if (backward && dtype != GMLM_F32 && cdiv(nch, g.lpr) >= 3) g.lpr = 64;
   g.ch = (int)cdiv(nch, g.lpr);
   return g;
 }
@@ -510,7 +513,7 @@ extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const 
   const float ks = dropout_keep_scale(th);
   const int blocks = ln_bwd_blocks(rows);
   float* partial = static_cast<float*>(workspace);
-  const LnGeom ge = ln_geom(f, dtype);
+  const LnGeom ge = ln_geom(f, dtype, true);
   const size_t lds = (size_t)4 * 3 * f * sizeof(float);
 #define L2(T, C, P, A) ln_bwd_kernel<T, C, P, A><<<blocks, 256, lds, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
 #define L(T, A) do { if (ge.lpr == 32) { if (ge.ch <= 1) L2(T, 1, 32, A); else if (ge.ch == 2) L2(T, 2, 32, A); else L2(T, 3, 32, A); } \
