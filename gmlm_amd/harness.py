@@ -72,6 +72,57 @@ def generate_active_node_mask(x, edge_index, mask_ratio, base_mask: Optional[tor
     return out
 
 
+def nt_xent_loss(z1, z2, temperature=0.5, batch_size=8):
+    """main.py:102-136 (chunked NT-Xent) without the Python loop over chunks: all full chunks of
+    ``batch_size`` rows go through one batched [chunks, 2b, 2b] similarity + cross-entropy; the ragged
+    last chunk (if any) is handled the same way on its own.  Chunks of a single row are skipped and every
+    chunk is weighted by its share of the rows, exactly like the reference."""
+    total = z1.size(0)
+    if total == 0:
+        return torch.tensor(0.0, device=z1.device, requires_grad=True)
+    b = batch_size if batch_size is not None else total
+
+    def chunk_losses(a1, a2, bc):                       # a*: [chunks, bc, P] -> mean CE per chunk
+        e = torch.cat([F.normalize(a1, dim=-1), F.normalize(a2, dim=-1)], dim=1)            # [chunks, 2bc, P]
+        sim = torch.bmm(e, e.transpose(1, 2)) / temperature
+        eye = torch.eye(2 * bc, dtype=torch.bool, device=z1.device)
+        sim = sim.masked_fill(eye, -float('inf'))
+        pos = torch.arange(bc, device=z1.device)
+        labels = torch.cat([pos + bc, pos]).expand(sim.size(0), -1)
+        return F.cross_entropy(sim.reshape(-1, 2 * bc), labels.reshape(-1), reduction='none').view(sim.size(0), -1).mean(1)
+
+    nfull, rem = divmod(total, b)
+    loss, used = None, False
+    if nfull and b > 1:
+        lf = chunk_losses(z1[:nfull * b].view(nfull, b, -1).float(), z2[:nfull * b].view(nfull, b, -1).float(), b)
+        loss, used = lf.sum() * (b / total), True
+    if rem > 1:
+        lr = chunk_losses(z1[nfull * b:].unsqueeze(0).float(), z2[nfull * b:].unsqueeze(0).float(), rem)
+        loss = lr.sum() * (rem / total) + (loss if loss is not None else 0.0)
+        used = True
+    if not used:
+        return torch.tensor(0.0, device=z1.device, requires_grad=True)
+    return loss
+
+
+def pretrain_step(model, optimizer, x, edge_index, mask1, mask2, *, beta=0.7, temperature=0.5, autocast=True):
+    """One iteration of ``pretrain_contrastive_gnn`` (main.py:438-456): two soft-masked views ->
+    ``get_graph_embeddings`` twice (the graph preprocessing is cached, not redone per view) -> NT-Xent."""
+    model.train()
+    optimizer.zero_grad(set_to_none=True)
+    with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
+        g1 = model.get_graph_embeddings(model.soft_mask_input(x, mask1, beta), edge_index, edge_type=None)
+        g2 = model.get_graph_embeddings(model.soft_mask_input(x, mask2, beta), edge_index, edge_type=None)
+        loss = nt_xent_loss(g1, g2, temperature=temperature, batch_size=8)
+    if not bool(torch.isfinite(loss)):
+        return float(loss)
+    loss.backward()
+    if model.dist is not None:
+        model.dist.all_reduce_grads(model)
+    optimizer.step()
+    return float(loss.detach())
+
+
 @dataclass
 class StepResult:
     loss: float

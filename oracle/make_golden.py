@@ -131,6 +131,9 @@ def run_model_case(main, scratch, name, n, e, f_in, hc, c, plm, seed, store_full
     )
     for k, v in cap.items():
         out[k] = v.numpy()
+    if store_full_grads:   # toy case: keep the raw texts + vocabulary so the text -> tokenizer -> model path is testable
+        out["texts"] = np.array(texts, dtype=np.str_)
+        out["vocab"] = np.array(VOCAB, dtype=np.str_)
     gn = {}
     for k, p in model.named_parameters():
         if p.grad is None:

@@ -244,3 +244,28 @@ def test_large_power_law_graph_embeddings_vs_oracle(dev):
             continue
         rn, gn = float(r.double().norm()), float(p.grad.double().norm())
         assert abs(rn - gn) <= 2e-3 * max(rn, 1e-4) + 1e-6, (k, gn, rn)
+
+
+def test_text_list_drop_in_path(dev):
+    """forward(..., all_node_texts: list[str], ...) exactly as the reference calls it (main.py:545): host
+    tokenisation with the HF tokenizer (once, cached), then the device pipeline.  Texts / vocabulary come
+    from the golden fixture, whose logits were produced by main.GraphTextLM on the same strings."""
+    from transformers import BertTokenizer
+    import gmlm_amd
+    g = load_golden("g1_toy")
+    cfg = g["config"]
+    tok = BertTokenizer(vocab={w: i for i, w in enumerate(g["vocab"].tolist())})
+    m = gmlm_amd.GraphTextLM(cfg["f_in"], cfg["hc"], cfg["c"], dropout_rate=0.0, plm_encoder=hf_bert(cfg["plm"]),
+                             plm_tokenizer=tok, plm_max_length=cfg["max_len"])
+    m.load_state_dict(recipe_state_dict(model_state_template(cfg["f_in"], cfg["hc"], cfg["c"], cfg["plm"]), cfg["seed"]))
+    m = m.to(dev).eval()
+    texts = g["texts"].tolist()
+    tt = m.tokenize(texts)
+    assert np.array_equal(tt.lens.cpu().numpy(), g["attention_mask"].sum(-1))
+    l = tt.input_ids.shape[1]
+    assert np.array_equal(tt.input_ids.cpu().numpy(), g["input_ids"][:, :l])          # token ids: bit-exact
+    with torch.no_grad():
+        logits = m(t(g["x_soft_masked"]).to(dev), t(g["edge_index"]).to(dev), texts, t(g["node_mask"]).to(dev),
+                   plm_batch_size=cfg["plm_batch_size"])
+    np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
+    assert m.tokenize(texts) is tt                                                       # cached by list identity

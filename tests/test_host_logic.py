@@ -1,0 +1,38 @@
+"""CPU tests of host-side logic that needs no GPU: NT-Xent restatement vs the golden value produced by
+main.nt_xent_loss, the .npz reader's layout / split, optimizer grouping helper."""
+import numpy as np
+import torch
+
+from helpers import load_golden, t
+
+
+def test_nt_xent_matches_reference_golden():
+    from gmlm_amd.harness import nt_xent_loss
+    g = load_golden("g5_funcs")
+    z1, z2 = t(g["ntx_z1"]), t(g["ntx_z2"])                     # 21 rows: two full chunks of 8 + a ragged chunk of 5
+    assert abs(float(nt_xent_loss(z1, z2, 0.5, 8)) - float(g["ntx_loss"])) < 1e-5
+    assert float(nt_xent_loss(z1[:0], z2[:0])) == 0.0
+    assert float(nt_xent_loss(z1[:1], z2[:1])) == 0.0            # single-row chunk is skipped (main.py:117)
+    z1.requires_grad_(True)
+    nt_xent_loss(z1, z2, 0.5, 8).backward()
+    assert torch.isfinite(z1.grad).all()
+
+
+def test_npz_reader_layout_and_split(tmp_path):
+    from gmlm_amd.data import load_npz_dataset
+    n = 50
+    rng = np.random.RandomState(0)
+    path = tmp_path / "toy.npz"
+    np.savez(path, node_features=rng.randn(n, 7).astype(np.float32), edges=rng.randint(0, n, (2, 120)),
+             node_labels=rng.randint(0, 3, n), node_texts=np.array([f"text {i}" for i in range(n)]),
+             label_texts=np.array(["a", "b", "c"]), train_masks=np.zeros(n, bool), val_masks=np.zeros(n, bool),
+             test_masks=np.ones(n, bool))
+    data, nf, nc = load_npz_dataset(str(path), split_ratios=(0.48, 0.32, 0.20), seed=42)
+    assert (nf, nc, data.num_nodes) == (7, 3, n) and data.node_texts[3] == "text 3"
+    idx = np.arange(n)
+    np.random.RandomState(42).shuffle(idx)                       # main.py:793-795
+    assert np.array_equal(np.sort(data.train_mask.nonzero().flatten().numpy()), np.sort(idx[:24]))
+    assert int(data.train_mask.sum() + data.val_mask.sum() + data.test_mask.sum()) == n
+    assert not bool((data.train_mask & data.val_mask).any())
+    data2, _, _ = load_npz_dataset(str(path))
+    assert bool(data2.test_mask.all()) and not bool(data2.train_mask.any())
