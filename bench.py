@@ -215,6 +215,48 @@ def _micro_attn(dev, args, out):
         del q, k, v, go, y
 
 
+def gnn_large(dev, args):
+    """get_graph_embeddings forward+backward on one GPU's share of the 10M-node S5 config (SURVEY.md §8d:
+    reported separately because the N x N cross-attention, not the GNN, bounds the full model at that size):
+    power-law graph, F_in = 768, hidden_channels = args.hc, bf16, reference dropout, activation checkpointing
+    like the reference (main.py:278-314)."""
+    import gmlm_amd
+    from transformers import BertConfig, BertModel
+    n, e, f_in = args.micro_nodes, args.micro_edges, 768
+    g = torch.Generator(device=dev).manual_seed(6)
+    w = (torch.arange(n, device=dev, dtype=torch.float32) + 1.0).pow(-1.0 / 1.2)
+    perm = torch.randperm(n, device=dev, generator=g)
+    ei = torch.stack([perm[torch.multinomial(w, e, replacement=True, generator=g)],
+                      perm[torch.multinomial(w, e, replacement=True, generator=g)]])
+    del w, perm
+    x = torch.randn(n, f_in, device=dev)
+    mask = torch.rand(n, device=dev) < 0.3
+    enc = BertModel(BertConfig(vocab_size=64, hidden_size=args.plm_hidden, num_hidden_layers=1,
+                               num_attention_heads=args.plm_hidden // 64, intermediate_size=64, max_position_embeddings=16))
+    torch.manual_seed(0)
+    m = gmlm_amd.GraphTextLM(f_in, args.hc, 16, dropout_rate=0.3, plm_encoder=enc, compute_dtype=torch.bfloat16,
+                             activation_checkpointing=True).to(dev).train()
+
+    def step():
+        m.zero_grad(set_to_none=True)
+        out = m.get_graph_embeddings(m.soft_mask_input(x, mask, 0.7), ei)
+        out.float().square().mean().backward()
+
+    torch.cuda.reset_peak_memory_stats()
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    csr = m.graph(ei, n)
+    return {"workload": f"get_graph_embeddings fwd+bwd, power-law graph N={n} E={e} F_in={f_in} hidden_channels={args.hc} bf16, "
+                        f"activation checkpointing, R_a={csr.r_active}",
+            "nodes_per_s": round(n / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
+
+
 def _pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_spmm_traffic.json); None if absent."""
     try:
@@ -244,6 +286,7 @@ def main():
     ap.add_argument("--no-micro", action="store_true", help="skip the kernel micro-benchmarks (rank 0, N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = 1-GPU rehearsal of the N>1 path)")
     ap.add_argument("--micro-only", action="store_true")
+    ap.add_argument("--gnn-large", action="store_true", help="GNN-only step on a 1.25M-node S5 shard (single GPU)")
     ap.add_argument("--micro-select", default="spmm,attn", help="comma list of micro-benchmark groups: spmm, attn")
     ap.add_argument("--micro-nodes", type=int, default=1_250_000)
     ap.add_argument("--micro-edges", type=int, default=12_500_000)
@@ -268,6 +311,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    if args.gnn_large:
+        print(json.dumps({"gnn_large": gnn_large(dev, args)}))
+        return
     if args.micro_only:
         print(json.dumps({"micro": micro(dev, args)}))
         return

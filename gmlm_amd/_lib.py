@@ -35,7 +35,7 @@ SIGNATURES = {
     "gmlm_basis_compose_bwd_workspace_bytes": (_sz, [_i32, _i32, _i64]),
     "gmlm_basis_compose_bwd": (C.c_int, [_p, _p, _p, _i32, _i32, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_colstats_workspace_bytes": (_sz, [_i64, _i64]),
-    "gmlm_colstats": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "gmlm_colstats": (C.c_int, [_p, _i32, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_graphnorm_finalize": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _p, _p, _p]),
     "gmlm_graphnorm_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _i32, _p]),
     "gmlm_graphnorm_bwd_stats": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _sz, _p]),

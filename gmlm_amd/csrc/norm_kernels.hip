@@ -13,12 +13,13 @@ namespace gmlm {
 // ------------------------------------------------------------------------------------------------
 // GraphNorm
 // ------------------------------------------------------------------------------------------------
+template <typename T>
 struct ColStatsFn {
-  const float* x;
+  const T* x;
   const float* shift;
   int64_t f;
   __device__ void operator()(int64_t r, int64_t c, float (&v)[2]) const {
-    const float d = x[r * f + c] - (shift ? shift[c] : 0.f);
+    const float d = Store<T>::ld(x + r * f + c) - (shift ? shift[c] : 0.f);
     v[0] = d;
     v[1] = d * d;
   }
@@ -41,7 +42,7 @@ __global__ void graphnorm_finalize_kernel(const float* __restrict__ s1, const fl
 
 // rows stream through a block; thread <-> column (params in registers).
 template <typename TY, bool ACT>
-__global__ __launch_bounds__(256) void graphnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+__global__ __launch_bounds__(256) void graphnorm_apply_kernel(const TY* __restrict__ x, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ ms,
                                                                int64_t n, int64_t f, uint32_t thresh, float keep_scale,
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256) void graphnorm_apply_kernel(const float* __res
   const float bb = b[c];
   for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
     const int64_t i = r * f + c;
-    float v = (x[i] - sub) * a + bb;
+    float v = (Store<TY>::ld(x + i) - sub) * a + bb;
     if (ACT) v = gelu_erf(v);
     if (thresh) v *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
     Store<TY>::st(y + i, v);
@@ -63,14 +64,15 @@ __global__ __launch_bounds__(256) void graphnorm_apply_kernel(const float* __res
 template <typename TG, bool ACT>
 struct GraphNormBwdStatsFn {
   const TG* g;
-  const float *x, *mean, *rstd, *w, *b, *ms;
+  const TG* x;
+  const float *mean, *rstd, *w, *b, *ms;
   int64_t f;
   uint32_t thresh;
   float keep_scale;
   uint64_t seed;
   __device__ void operator()(int64_t r, int64_t c, float (&v)[2]) const {
     const int64_t i = r * f + c;
-    const float oh = (x[i] - mean[c] * ms[c]) * rstd[c];
+    const float oh = (Store<TG>::ld(x + i) - mean[c] * ms[c]) * rstd[c];
     float gz = Store<TG>::ld(g + i);
     if (thresh) gz *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
     if (ACT) gz *= gelu_erf_grad(w[c] * oh + b[c]);
@@ -81,9 +83,9 @@ struct GraphNormBwdStatsFn {
 
 template <typename TG, bool ACT>
 __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
-    const TG* __restrict__ g, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const TG* __restrict__ g, const TG* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ ms, const float* __restrict__ gs,
-    int64_t n, int64_t n_total, int64_t f, uint32_t thresh, float keep_scale, uint64_t seed, float* __restrict__ dx,
+    int64_t n, int64_t n_total, int64_t f, uint32_t thresh, float keep_scale, uint64_t seed, TG* __restrict__ dx,
     float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dms) {
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= f) return;
@@ -101,11 +103,11 @@ __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
   const float sub = mu * msc;
   for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
     const int64_t i = r * f + c;
-    const float oh = (x[i] - sub) * rs;
+    const float oh = (Store<TG>::ld(x + i) - sub) * rs;
     float gz = Store<TG>::ld(g + i);
     if (thresh) gz *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
     if (ACT) gz *= gelu_erf_grad(wc * oh + bc);
-    dx[i] = wc * rs * (gz - oh * m2) - msc * mean_do;
+    Store<TG>::st(dx + i, wc * rs * (gz - oh * m2) - msc * mean_do);
   }
 }
 
@@ -374,11 +376,14 @@ using namespace gmlm;
 
 extern "C" size_t gmlm_colstats_workspace_bytes(int64_t n, int64_t f) { return col_reduce_workspace_bytes(n, f, 2); }
 
-extern "C" int gmlm_colstats(const float* x, const float* shift, int64_t n, int64_t f, float* s1, float* s2,
+extern "C" int gmlm_colstats(const void* x, int dtype, const float* shift, int64_t n, int64_t f, float* s1, float* s2,
                              void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
   GMLM_REQUIRE(n >= 0 && f > 0 && s1 && s2 && (n == 0 || x), "colstats: bad arguments");
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "colstats: unsupported dtype");
   GMLM_REQUIRE(s2 == s1 + f, "colstats: s1 and s2 must be the two rows of one [2, f] buffer");
-  return col_reduce<2>(n, f, ColStatsFn{x, shift, f}, s1, workspace, workspace_bytes, as_stream(stream));
+  if (dtype == GMLM_F32)
+    return col_reduce<2>(n, f, ColStatsFn<float>{(const float*)x, shift, f}, s1, workspace, workspace_bytes, as_stream(stream));
+  return col_reduce<2>(n, f, ColStatsFn<bf16_t>{(const bf16_t*)x, shift, f}, s1, workspace, workspace_bytes, as_stream(stream));
 }
 
 extern "C" int gmlm_graphnorm_finalize(const float* s1, const float* s2, const float* shift, const float* mean_scale,
@@ -399,7 +404,7 @@ static inline dim3 col_stream_grid(int64_t n, int64_t f) {
   return dim3(ct, (unsigned)ry);
 }
 
-extern "C" int gmlm_graphnorm_apply(const float* x, const float* mean, const float* rstd, const float* weight,
+extern "C" int gmlm_graphnorm_apply(const void* x, const float* mean, const float* rstd, const float* weight,
                                     const float* bias, const float* mean_scale, int64_t n, int64_t f, int act,
                                     float dropout_p, uint64_t seed, void* y, int dtype, gmlm_stream_t stream) {
   GMLM_REQUIRE(n >= 0 && f > 0, "graphnorm_apply: bad sizes");
@@ -411,7 +416,7 @@ extern "C" int gmlm_graphnorm_apply(const float* x, const float* mean, const flo
   const float ks = dropout_keep_scale(th);
   const dim3 grid = col_stream_grid(n, f);
   hipStream_t st = as_stream(stream);
-#define L(TY, A) graphnorm_apply_kernel<TY, A><<<grid, 256, 0, st>>>(x, mean, rstd, weight, bias, mean_scale, n, f, th, ks, seed, (TY*)y)
+#define L(TY, A) graphnorm_apply_kernel<TY, A><<<grid, 256, 0, st>>>((const TY*)x, mean, rstd, weight, bias, mean_scale, n, f, th, ks, seed, (TY*)y)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
@@ -419,7 +424,7 @@ extern "C" int gmlm_graphnorm_apply(const float* x, const float* mean, const flo
   return GMLM_OK;
 }
 
-extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const float* x, const float* mean, const float* rstd,
+extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                                         const float* weight, const float* bias, const float* mean_scale, int64_t n,
                                         int64_t f, int act, float dropout_p, uint64_t seed, float* gs, void* workspace,
                                         size_t workspace_bytes, gmlm_stream_t stream) {
@@ -429,16 +434,16 @@ extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const float* x
   const uint32_t th = dropout_threshold(dropout_p);
   const float ks = dropout_keep_scale(th);
   hipStream_t st = as_stream(stream);
-#define L(TG, A) return col_reduce<2>(n, f, GraphNormBwdStatsFn<TG, A>{(const TG*)g, x, mean, rstd, weight, bias, mean_scale, f, th, ks, seed}, gs, workspace, workspace_bytes, st)
+#define L(TG, A) return col_reduce<2>(n, f, GraphNormBwdStatsFn<TG, A>{(const TG*)g, (const TG*)x, mean, rstd, weight, bias, mean_scale, f, th, ks, seed}, gs, workspace, workspace_bytes, st)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
 }
 
-extern "C" int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const float* x, const float* mean, const float* rstd,
+extern "C" int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                                         const float* weight, const float* bias, const float* mean_scale, const float* gs,
                                         int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed,
-                                        float* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream) {
+                                        void* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream) {
   GMLM_REQUIRE(n >= 0 && n_total >= n && n_total > 0 && f > 0 && gs, "graphnorm_bwd_apply: bad arguments");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_bwd_apply: unsupported dtype");
   GMLM_REQUIRE(mean && rstd && weight && bias && mean_scale && (n == 0 || (g && x && dx)), "graphnorm_bwd_apply: null pointer");
@@ -446,7 +451,7 @@ extern "C" int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const float* x
   const float ks = dropout_keep_scale(th);
   dim3 grid = col_stream_grid(n > 0 ? n : 1, f);
   hipStream_t st = as_stream(stream);
-#define L(TG, A) graphnorm_bwd_apply_kernel<TG, A><<<grid, 256, 0, st>>>((const TG*)g, x, mean, rstd, weight, bias, mean_scale, gs, n, n_total, f, th, ks, seed, dx, dweight, dbias, dmean_scale)
+#define L(TG, A) graphnorm_bwd_apply_kernel<TG, A><<<grid, 256, 0, st>>>((const TG*)g, (const TG*)x, mean, rstd, weight, bias, mean_scale, gs, n, n_total, f, th, ks, seed, (TG*)dx, dweight, dbias, dmean_scale)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L

@@ -115,13 +115,13 @@ class GraphTextLM(nn.Module):
         conv, norm, drop = getattr(self, f"rgcn{k}"), getattr(self, f"gnorm{k}"), getattr(self, f"dropout{k}")
         if self.dist is not None:
             x = self.dist.with_halo(x)                                # [n_local + n_halo, F]
-        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None)   # fp32 [n, out]
+        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None)   # [n, out] in cd
         cd = x.dtype
         n_total = self.dist.n_total if self.dist is not None else z.size(0)
         if n_total > 1:                                               # main.py:273 guard
             reducer = self.dist.all_reduce_sum if self.dist is not None else None
             return norm(z, act=True, dropout_p=drop.p, out_dtype=cd, reducer=reducer, n_total=n_total)
-        return ops.bias_gelu(z.to(cd), None, drop.p, self.training)
+        return ops.bias_gelu(z, None, drop.p, self.training)
 
     def get_graph_embeddings(self, x_feat, edge_index, edge_type=None):
         edge_index = edge_index.to(torch.long)

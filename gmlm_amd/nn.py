@@ -123,16 +123,16 @@ class RGCNConv(nn.Module):
         return w.reshape(-1, self.out_channels).to(dtype)
 
     def forward_csr(self, x: torch.Tensor, csr: RelCSR, reducer=None) -> torch.Tensor:
-        """x: [n_src, in (+pad)] in the compute dtype -> fp32 [n, out]."""
+        """x: [n_src, in (+pad)] in the compute dtype -> [n, out] in the same dtype (two accumulating
+        hipBLASLt GEMMs: bias + H W_cat, then += x root; no fp32 staging passes over [n, out])."""
         in_pad = x.shape[1] - self.in_channels
         n = csr.num_nodes
         h = ops.RGCNAggregate.apply(x, csr)                                   # [n, R_a*(in+pad)]
         with torch.autocast("cuda", enabled=False):
             w = self.relation_weights(csr, x.dtype, in_pad, reducer)
             root = self.root if not in_pad else F.pad(self.root, (0, 0, 0, in_pad))
-            out = torch.mm(h, w).float()
-            out = out + torch.mm(x[:n], root.to(x.dtype)).float()
-            return out + self.bias.float()
+            out = torch.addmm(self.bias.to(x.dtype), h, w)
+            return out.addmm_(x[:n], root.to(x.dtype))
 
     def forward(self, x, edge_index, edge_type):
         csr = _GRAPHS.get(edge_index, x.size(0), self.num_relations, edge_type)

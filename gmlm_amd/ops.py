@@ -195,7 +195,8 @@ class RGCNAggregate(torch.autograd.Function):
 # K4: GraphNorm + GELU + dropout
 # ---------------------------------------------------------------------------------------------
 class GraphNormAct(torch.autograd.Function):
-    """y = dropout(act(GraphNorm(z))).  z fp32 [n, f]; y in `out_dtype`.
+    """y = dropout(act(GraphNorm(z))).  z [n, f] in the compute dtype (the GEMM output feeds the kernels
+    directly: no fp32 staging copy); y and dz in the same dtype; statistics fp32.
 
     ``reducer``: optional callable(tensor) summing a small fp32 tensor over all ranks in place (the
     1-D node partition makes GraphNorm's column statistics global: SURVEY.md §8e); ``n_total`` is the
@@ -205,26 +206,27 @@ class GraphNormAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, z, weight, bias, mean_scale, eps, act, p, seed, out_dtype, reducer, n_total):
         _cuda(z)
-        z = z.float().contiguous()
+        z = z.to(out_dtype).contiguous()
         n, f = z.shape
         n_total = int(n_total) if n_total else n
         dev = z.device
         w, b, ms = _f32c(weight), _f32c(bias), _f32c(mean_scale)
         st = _stream()
+        dt = _dt(z)
         stats = torch.empty(2, f, dtype=torch.float32, device=dev)
         shift = None
         if reducer is None and n > 0:
-            shift = z[0].contiguous()          # shifted sums: no cancellation in E[o^2]
+            shift = z[0].float().contiguous()          # shifted sums: no cancellation in E[o^2]
         ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), dev)
-        check(lib().gmlm_colstats(_ptr(z), _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(), st),
+        check(lib().gmlm_colstats(_ptr(z), dt, _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(), st),
               "gmlm_colstats")
         if reducer is not None:
             # exact two-pass in the distributed case: all-reduce sum(x) -> mean, then sum((x - mean*ms)^2)
             reducer(stats)
             mu = stats[0] / n_total
             shift = (mu * ms).contiguous()
-            check(lib().gmlm_colstats(_ptr(z), _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(), st),
-                  "gmlm_colstats")
+            check(lib().gmlm_colstats(_ptr(z), dt, _ptr(shift), n, f, _ptr(stats[0]), _ptr(stats[1]), _ptr(ws), ws.numel(),
+                                      st), "gmlm_colstats")
             reducer(stats)
             mean = mu.contiguous()
             rstd = torch.rsqrt(stats[1] / n_total + eps).contiguous()
@@ -235,7 +237,7 @@ class GraphNormAct(torch.autograd.Function):
                                                 _ptr(mean), _ptr(rstd), st), "gmlm_graphnorm_finalize")
         y = torch.empty(n, f, dtype=out_dtype, device=dev)
         check(lib().gmlm_graphnorm_apply(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms), n, f, int(act),
-                                         float(p), seed, _ptr(y), _dt(y), st), "gmlm_graphnorm_apply")
+                                         float(p), seed, _ptr(y), dt, st), "gmlm_graphnorm_apply")
         ctx.save_for_backward(z, mean, rstd, w, b, ms)
         ctx.cfg = (int(act), float(p), seed, reducer, n_total)
         return y
@@ -244,40 +246,38 @@ class GraphNormAct(torch.autograd.Function):
     def backward(ctx, gy):
         z, mean, rstd, w, b, ms = ctx.saved_tensors
         act, p, seed, reducer, n_total = ctx.cfg
-        gy = gy.contiguous()
+        gy = gy.contiguous().to(z.dtype)
         n, f = z.shape
         dev = z.device
         st = _stream()
+        dt = _dt(z)
         gs = torch.empty(2, f, dtype=torch.float32, device=dev)
         ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), dev)
-        check(lib().gmlm_graphnorm_bwd_stats(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms),
+        check(lib().gmlm_graphnorm_bwd_stats(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms),
                                              n, f, act, p, seed, _ptr(gs), _ptr(ws), ws.numel(), st),
               "gmlm_graphnorm_bwd_stats")
         gs_local = gs
         if reducer is not None:
             gs_local = gs.clone()
             reducer(gs)
-        dz = torch.empty(n, f, dtype=torch.float32, device=dev)
+        dz = torch.empty(n, f, dtype=z.dtype, device=dev)
         if reducer is None:
             dw = torch.empty(f, dtype=torch.float32, device=dev)
             db = torch.empty_like(dw)
             dms = torch.empty_like(dw)
-            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
+            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
                                                  _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), _ptr(dw),
                                                  _ptr(db), _ptr(dms), st), "gmlm_graphnorm_bwd_apply")
         else:
-            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), _dt(gy), _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
+            check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
                                                  _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), None, None,
                                                  None, st), "gmlm_graphnorm_bwd_apply")
             # parameter grads: LOCAL contributions only (the gradient all-reduce sums them over ranks)
             dw, db = gs_local[1].clone(), gs_local[0].clone()
             m2 = gs[1] / n_total
-            mean_oh = mean * (1.0 - ms) * rstd
-            mean_do = w * rstd * (gs[0] / n_total - m2 * mean_oh)          # global mean_j do_j
             # sum over LOCAL rows of do_j = w*rstd*(sum_local gz - m2 * sum_local ohat)
-            sum_oh_local = (z.sum(0) - n * mean * ms) * rstd
+            sum_oh_local = (z.float().sum(0) - n * mean * ms) * rstd
             dms = -mean * (w * rstd * (gs_local[0] - m2 * sum_oh_local))
-            del mean_do
         return dz, dw, db, dms, None, None, None, None, None, None, None
 
 

@@ -121,10 +121,11 @@ int gmlm_basis_compose_bwd(const float* comp, const float* weight, const float* 
  * K4  GraphNorm (+ exact-erf GELU + dropout) forward / backward, single graph (batch = all rows)
  * replaces: torch_geometric.nn.GraphNorm.forward -> F.gelu -> nn.Dropout (main.py:273-275 ...)
  * ------------------------------------------------------------------------------------------- */
-/* Column statistics of x [n, f] (fp32): s1[c] = sum_i (x[i,c] - shift[c]), s2[c] = sum_i (x[i,c]-shift[c])^2.
- * shift may be NULL (= 0).  partial: workspace of gmlm_colstats_workspace_bytes(n, f). */
+/* Column statistics of x [n, f] (`dtype`): s1[c] = sum_i (x[i,c] - shift[c]), s2[c] = sum_i (x[i,c]-shift[c])^2
+ * (fp32).  shift may be NULL (= 0).  partial: workspace of gmlm_colstats_workspace_bytes(n, f).
+ * In all K4 entries x, y, g and dx share ONE storage dtype (the GEMM output feeds the norm directly). */
 size_t gmlm_colstats_workspace_bytes(int64_t n, int64_t f);
-int gmlm_colstats(const float* x, const float* shift, int64_t n, int64_t f, float* s1, float* s2,
+int gmlm_colstats(const void* x, int dtype, const float* shift, int64_t n, int64_t f, float* s1, float* s2,
                   void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
 /* mean[c], rstd[c] from (s1, s2, shift) over n_total rows:  mu = shift + s1/n; o = x - mu*ms;
  * var = E[o^2]; rstd = 1/sqrt(var + eps). */
@@ -132,20 +133,20 @@ int gmlm_graphnorm_finalize(const float* s1, const float* s2, const float* shift
                             int64_t n_total, int64_t f, float eps, float* mean, float* rstd, gmlm_stream_t stream);
 /* y = dropout(gelu(weight * (x - mean*ms) * rstd + bias)); y stored as `dtype`; act != 0 applies GELU.
  * dropout: keep-probability scaling 1/(1-p), mask = hash(seed, element index) (replayable). */
-int gmlm_graphnorm_apply(const float* x, const float* mean, const float* rstd, const float* weight,
+int gmlm_graphnorm_apply(const void* x, const float* mean, const float* rstd, const float* weight,
                          const float* bias, const float* mean_scale, int64_t n, int64_t f, int act,
                          float dropout_p, uint64_t seed, void* y, int dtype, gmlm_stream_t stream);
 /* backward, pass 1: column sums needed by the closed form.  g = dL/dy (dtype), x = saved pre-norm input.
  * gs[0,c] = sum_i gz[i,c], gs[1,c] = sum_i gz[i,c] * ohat[i,c]   (gz = g through dropout and GELU) */
-int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const float* x, const float* mean, const float* rstd,
+int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                              const float* weight, const float* bias, const float* mean_scale, int64_t n, int64_t f,
                              int act, float dropout_p, uint64_t seed, float* gs /* [2, f] */,
                              void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
-/* backward, pass 2: dx (fp32) and parameter grads from the (all-reduced) column sums over n_total rows. */
-int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const float* x, const float* mean, const float* rstd,
+/* backward, pass 2: dx (`dtype`) and parameter grads from the (all-reduced) column sums over n_total rows. */
+int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                              const float* weight, const float* bias, const float* mean_scale, const float* gs,
                              int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed,
-                             float* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream);
+                             void* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K6  fused bias + dropout + residual + LayerNorm (+ GELU) forward / backward (row-wise)
