@@ -278,7 +278,7 @@ def main():
     ap.add_argument("--plm-layers", type=int, default=12)
     ap.add_argument("--vocab", type=int, default=30522)
     ap.add_argument("--max-len", type=int, default=128)
-    ap.add_argument("--plm-batch", type=int, default=256)
+    ap.add_argument("--plm-batch", type=int, default=4096, help="text micro-batch (nodes); default = all active nodes in ONE packed batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-plm-sample", type=int, default=16)
     ap.add_argument("--cpu-hc", type=int, default=768)

@@ -112,13 +112,13 @@ def _mm(x, w, b=None):
         return _Linear.apply(x, w, b)
 
 
-def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps):
+def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0):
     pdim = h.shape[-1]
     d = pdim // heads
-    qkv = _mm(h, lw.wqkv, lw.bqkv)                                                  # [B, L, 3P]
+    qkv = _mm(h, lw.wqkv, lw.bqkv)                                                  # [B, L, 3P] or packed [T, 3P]
     scale = d ** -0.5
     if d in (64, 96):
-        ctx = ops.attention_qkv(qkv, lens, heads, scale, p_attn, training)
+        ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len)
     else:
         ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
                                 training)
@@ -152,6 +152,32 @@ def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtyp
             h = checkpoint(_layer, lw, h, lens, heads, training, p_hidden, p_attn, eps, use_reentrant=False)
         else:
             h = _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps)
+    return h
+
+
+def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
+                       cd: torch.dtype, training: bool = False, gradient_checkpointing: bool = False, weights=None):
+    """Variable-length (packed) encoder pass: ``token_ids`` int [T] = the valid tokens of all sequences back to
+    back, ``pos_ids`` int [T] = position of each token inside its sequence, ``cu_seqlens`` int32 [B+1].
+    Returns [T, P].  Every GEMM / LayerNorm / GELU row is a real token and attention never sees padding
+    (same result per token as the padded form: padded keys have probability exactly 0 there)."""
+    cfg = plm.config
+    emb = plm.embeddings
+    x = torch.nn.functional.embedding(token_ids.long(), emb.word_embeddings.weight)
+    x = x + emb.token_type_embeddings.weight[0] + torch.nn.functional.embedding(pos_ids.long(), emb.position_embeddings.weight)
+    eps, p_hidden, p_attn = cfg.layer_norm_eps, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
+    h = ops.bias_res_layernorm(x.to(cd), None, None, emb.LayerNorm.weight, emb.LayerNorm.bias, eps, False, p_hidden, training)
+    heads = cfg.num_attention_heads
+    d = cfg.hidden_size // heads
+    if d not in (64, 96):
+        raise NotImplementedError("packed encoder pass needs head dim 64 or 96 (use the padded path otherwise)")
+    if weights is None:
+        weights = prepare_weights(plm, cd)
+    for lw in weights:
+        if gradient_checkpointing and training and torch.is_grad_enabled():
+            h = checkpoint(_layer, lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, use_reentrant=False)
+        else:
+            h = _layer(lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len)
     return h
 
 

@@ -30,6 +30,7 @@ struct AttnParams {
   const void *q, *k, *v, *out, *dout;
   const float* lse;
   const int32_t* kv_len;
+  const int32_t* cu;      // varlen (packed) mode: sequence b owns rows [cu[b], cu[b+1]) of q AND k/v; lq = total rows
   float* delta;
   void *o_w, *dq, *dk, *dv;
   float* lse_w;
@@ -40,6 +41,19 @@ struct AttnParams {
   float keep_scale;
   uint64_t seed;
 };
+
+// per-(batch, head) view: padded layout [b, l, ...] or packed layout (cu_seqlens)
+__device__ __forceinline__ void seq_view(const AttnParams& p, int64_t b, int64_t hd, int64_t& lq_, int64_t& lk_, int64_t& qbase,
+                                         int64_t& kbase, int64_t& lse_base) {
+  if (p.cu) {
+    qbase = kbase = p.cu[b];
+    lq_ = lk_ = p.cu[b + 1] - p.cu[b];
+    lse_base = hd * p.lq + qbase;                 // lse / delta laid out [h, total_rows]
+  } else {
+    qbase = b * p.lq; kbase = b * p.lk; lq_ = p.lq; lk_ = p.lk;
+    lse_base = (b * p.h + hd) * p.lq;             // [b, h, lq]
+  }
+}
 
 template <typename T> struct Pad;
 template <> struct Pad<bf16_t> { static constexpr int v = 8; };
@@ -216,13 +230,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) T vs[NBUF][KT * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  if ((int64_t)blockIdx.x * (NW * 32) >= (false ? lk_ : lq_)) return;   // varlen: tile past this sequence (block-uniform)
   const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
-  const bool q_ok = q_row < p.lq;
-  int64_t kvlen = p.lk;
-  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
-  const T* qg = static_cast<const T*>(p.q) + (b * p.lq + (q_ok ? q_row : 0)) * p.q_stride + hd * D;
-  const T* kg = static_cast<const T*>(p.k) + b * p.lk * p.k_stride + hd * D;
-  const T* vg = static_cast<const T*>(p.v) + b * p.lk * p.v_stride + hd * D;
+  const bool q_ok = q_row < lq_;
+  int64_t kvlen = lk_;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
+  const T* qg = static_cast<const T*>(p.q) + (qbase + (q_ok ? q_row : 0)) * p.q_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
   RowFrag<T, D> qf;
   qf.load(qg, q_ok, h);
   f32x16 o[DB];
@@ -232,13 +249,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m = -INFINITY, l = 0.f;              // running max / sum in the log2 domain (scores * scale * log2 e)
   const float sl2 = p.scale * kLog2e;
-  const uint32_t qmix = (uint32_t)((b * p.h + hd) * p.lq + q_row) * 0x9E3779B1u;
+  const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   const int ntiles = (int)((kvlen + KT - 1) / KT);
   TileRegs<T, D, KT, NT> kr, vr;
   if (ntiles > 0) {
-    kr.load(kg, p.k_stride, 0, p.lk, tid);
-    vr.load(vg, p.v_stride, 0, p.lk, tid);
+    kr.load(kg, p.k_stride, 0, lk_, tid);
+    vr.load(vg, p.v_stride, 0, lk_, tid);
     kr.store(ks[0], tid);
     vr.store(vs[0], tid);
   }
@@ -248,8 +265,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     const int cur = DBUF ? (t & 1) : 0;
     const bool more = t + 1 < ntiles;
     if (DBUF && more) {
-      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
-      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
     }
     f32x16 s[2];
 #pragma unroll
@@ -319,8 +336,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
       __syncthreads();
     } else if (more) {
       __syncthreads();
-      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
-      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
       kr.store(ks[0], tid);
       vr.store(vs[0], tid);
       __syncthreads();
@@ -328,10 +345,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   }
   if (q_ok) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
-    T* og = static_cast<T*>(p.o_w) + ((b * p.lq + q_row) * p.h + hd) * D;
+    T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
-    if (h == 0 && p.lse_w) p.lse_w[(b * p.h + hd) * p.lq + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
+    if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
   }
 }
 
@@ -359,7 +376,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
   for (int off = lanes >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
   if (row < rows && c == 0) {
     const int64_t hd = row % hn, bq = row / hn, q = bq % lq, b = bq / lq;
-    delta[(b * hn + hd) * lq + q] = acc;
+    delta[(b * hn + hd) * lq + q] = acc;         // packed mode passes b = 1, lq = total rows: [h, total_rows]
   }
 }
 
@@ -376,20 +393,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) T vs[NBUF][KT * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  if ((int64_t)blockIdx.x * (NW * 32) >= (false ? lk_ : lq_)) return;   // varlen: tile past this sequence (block-uniform)
   const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
-  const bool q_ok = q_row < p.lq;
-  int64_t kvlen = p.lk;
-  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
+  const bool q_ok = q_row < lq_;
+  int64_t kvlen = lk_;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
   const int64_t qr = q_ok ? q_row : 0;
-  const T* kg = static_cast<const T*>(p.k) + b * p.lk * p.k_stride + hd * D;
-  const T* vg = static_cast<const T*>(p.v) + b * p.lk * p.v_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
   RowFrag<T, D> qf, dof;
-  qf.load(static_cast<const T*>(p.q) + (b * p.lq + qr) * p.q_stride + hd * D, q_ok, h);
-  dof.load(static_cast<const T*>(p.dout) + ((b * p.lq + qr) * p.h + hd) * D, q_ok, h);
+  qf.load(static_cast<const T*>(p.q) + (qbase + qr) * p.q_stride + hd * D, q_ok, h);
+  dof.load(static_cast<const T*>(p.dout) + ((qbase + qr) * p.h + hd) * D, q_ok, h);
   const float sl2 = p.scale * kLog2e;
-  const float lse2 = q_ok ? p.lse[(b * p.h + hd) * p.lq + q_row] * kLog2e : 0.f;
-  const float dl = q_ok ? p.delta[(b * p.h + hd) * p.lq + q_row] : 0.f;
-  const uint32_t qmix = (uint32_t)((b * p.h + hd) * p.lq + q_row) * 0x9E3779B1u;
+  const float lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : 0.f;
+  const float dl = q_ok ? p.delta[lse_base + q_row] : 0.f;
+  const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   f32x16 dq[DB];
 #pragma unroll
@@ -399,8 +419,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   const int ntiles = (int)((kvlen + KT - 1) / KT);
   TileRegs<T, D, KT, NT> kr, vr;
   if (ntiles > 0) {
-    kr.load(kg, p.k_stride, 0, p.lk, tid);
-    vr.load(vg, p.v_stride, 0, p.lk, tid);
+    kr.load(kg, p.k_stride, 0, lk_, tid);
+    vr.load(vg, p.v_stride, 0, lk_, tid);
     kr.store(ks[0], tid);
     vr.store(vs[0], tid);
   }
@@ -410,8 +430,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
     const int cur = DBUF ? (t & 1) : 0;
     const bool more = t + 1 < ntiles;
     if (DBUF && more) {
-      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
-      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
     }
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
@@ -437,15 +457,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
       __syncthreads();
     } else if (more) {
       __syncthreads();
-      kr.load(kg, p.k_stride, kv0 + KT, p.lk, tid);
-      vr.load(vg, p.v_stride, kv0 + KT, p.lk, tid);
+      kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
+      vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
       kr.store(ks[0], tid);
       vr.store(vs[0], tid);
       __syncthreads();
     }
   }
   if (q_ok) {
-    T* og = static_cast<T*>(p.dq) + (b * p.lq + q_row) * p.dq_stride + hd * D;
+    T* og = static_cast<T*>(p.dq) + (qbase + q_row) * p.dq_stride + hd * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, dq[d], p.scale, h);
   }
@@ -466,19 +486,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   __shared__ float dl_s[NBUF][QT];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
-  int64_t kvlen = p.lk;
-  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > p.lk) kvlen = p.lk; if (kvlen < 0) kvlen = 0; }
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  if ((int64_t)blockIdx.x * (NW * 32) >= (true ? lk_ : lq_)) return;   // varlen: tile past this sequence (block-uniform)
+  int64_t kvlen = lk_;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
   const int64_t key = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
-  const bool key_in = key < p.lk;           // row exists in memory
+  const bool key_in = key < lk_;           // row exists in memory
   const bool key_ok = key < kvlen;          // takes part in the softmax
   const int64_t kr_ = key_in ? key : 0;
   RowFrag<T, D> kf, vf;
-  kf.load(static_cast<const T*>(p.k) + (b * p.lk + kr_) * p.k_stride + hd * D, key_in, h);
-  vf.load(static_cast<const T*>(p.v) + (b * p.lk + kr_) * p.v_stride + hd * D, key_in, h);
-  const T* qg = static_cast<const T*>(p.q) + b * p.lq * p.q_stride + hd * D;
-  const T* dog = static_cast<const T*>(p.dout) + (b * p.lq * p.h + hd) * D;
-  const float* lse_g = p.lse + (b * p.h + hd) * p.lq;
-  const float* dl_g = p.delta + (b * p.h + hd) * p.lq;
+  kf.load(static_cast<const T*>(p.k) + (kbase + kr_) * p.k_stride + hd * D, key_in, h);
+  vf.load(static_cast<const T*>(p.v) + (kbase + kr_) * p.v_stride + hd * D, key_in, h);
+  const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
+  const T* dog = static_cast<const T*>(p.dout) + (qbase * p.h + hd) * D;
+  const float* lse_g = p.lse + lse_base;
+  const float* dl_g = p.delta + lse_base;
   const float sl2 = p.scale * kLog2e;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   f32x16 dk[DB], dv[DB];
@@ -489,12 +512,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   // a whole workgroup past kv_len has nothing to accumulate (block-uniform condition)
   const bool block_live = (int64_t)blockIdx.x * (NW * 32) < kvlen;
   if (block_live) {
-    const int ntiles = (int)((p.lq + QT - 1) / QT);
+    const int ntiles = (int)((lq_ + QT - 1) / QT);
     TileRegs<T, D, QT, NT> qr, dor;
     float lr = 0.f, dr = 0.f;
     auto load_small = [&](int64_t q0) {
       if (tid < QT) {
-        const bool ok = q0 + tid < p.lq;
+        const bool ok = q0 + tid < lq_;
         lr = ok ? lse_g[q0 + tid] * kLog2e : 0.f;
         dr = ok ? dl_g[q0 + tid] : 0.f;
       }
@@ -503,8 +526,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
       if (tid < QT) { lse_s[buf][tid] = lr; dl_s[buf][tid] = dr; }
     };
     if (ntiles > 0) {
-      qr.load(qg, p.q_stride, 0, p.lq, tid);
-      dor.load(dog, p.h * D, 0, p.lq, tid);
+      qr.load(qg, p.q_stride, 0, lq_, tid);
+      dor.load(dog, p.h * D, 0, lq_, tid);
       load_small(0);
       qr.store(qs[0], tid);
       dor.store(dos[0], tid);
@@ -516,8 +539,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
       const int cur = DBUF ? (t & 1) : 0;
       const bool more = t + 1 < ntiles;
       if (DBUF && more) {
-        qr.load(qg, p.q_stride, q0 + QT, p.lq, tid);
-        dor.load(dog, p.h * D, q0 + QT, p.lq, tid);
+        qr.load(qg, p.q_stride, q0 + QT, lq_, tid);
+        dor.load(dog, p.h * D, q0 + QT, lq_, tid);
         load_small(q0 + QT);
       }
       f32x16 s, dp;
@@ -528,8 +551,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int qi = acc_row(i, h);
-        const float pr = (key_ok && q0 + qi < p.lq) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
-        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)((b * p.h + hd) * p.lq + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        const float pr = (key_ok && q0 + qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
+        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
         s[i] = pr * ms;
         dp[i] = pr * (dp[i] * ms - dl_s[cur][qi]);
       }
@@ -544,8 +567,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         __syncthreads();
       } else if (more) {
         __syncthreads();
-        qr.load(qg, p.q_stride, q0 + QT, p.lq, tid);
-        dor.load(dog, p.h * D, q0 + QT, p.lq, tid);
+        qr.load(qg, p.q_stride, q0 + QT, lq_, tid);
+        dor.load(dog, p.h * D, q0 + QT, lq_, tid);
         load_small(q0 + QT);
         qr.store(qs[0], tid);
         dor.store(dos[0], tid);
@@ -555,8 +578,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
     }
   }
   if (key_in) {
-    T* dkg = static_cast<T*>(p.dk) + (b * p.lk + key) * p.dk_stride + hd * D;
-    T* dvg = static_cast<T*>(p.dv) + (b * p.lk + key) * p.dv_stride + hd * D;
+    T* dkg = static_cast<T*>(p.dk) + (kbase + key) * p.dk_stride + hd * D;
+    T* dvg = static_cast<T*>(p.dv) + (kbase + key) * p.dv_stride + hd * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) {
       store_t<T>(dkg + d * 32, dk[d], p.scale, h);
@@ -609,8 +632,9 @@ static inline int pick_waves(int64_t rows, int64_t bh) { return cdiv(rows, 128) 
 extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                                   int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                                   float scale, float dropout_p, uint64_t seed, void* out, float* lse, int dtype,
-                                  gmlm_stream_t stream) {
+                                  const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream) {
   int rc = attn_check("attention_fwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_fwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_fwd: dropout_p must be in [0,1)");
   GMLM_REQUIRE(scale > 0.f, "attention_fwd: scale must be positive");
   if (rc != GMLM_OK) return rc;
@@ -622,16 +646,17 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   }
   GMLM_REQUIRE(out && aligned16(out), "attention_fwd: null or misaligned out");
   AttnParams p{};
-  p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.lse_w = lse;
+  p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.lse_w = lse; p.cu = cu_seqlens;
+  const int64_t rows_q = cu_seqlens ? max_len : lq;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale;
   p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
   hipStream_t st = as_stream(stream);
-  if (pick_waves(lq, b * h) == 4) {
-    dim3 grid((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+  if (pick_waves(rows_q, b * h) == 4) {
+    dim3 grid((unsigned)cdiv(rows_q, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_fwd_kernel, 4, grid, st, p);
   } else {
-    dim3 grid((unsigned)cdiv(lq, 64), (unsigned)(b * h));
+    dim3 grid((unsigned)cdiv(rows_q, 64), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_fwd_kernel, 2, grid, st, p);
   }
   GMLM_LAUNCH_CHECK();
@@ -646,9 +671,11 @@ extern "C" size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64
 extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                                   const float* lse, const int32_t* kv_len, int64_t b, int64_t h, int64_t lq, int64_t lk,
                                   int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
-                                  float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, int dtype,
+                                  float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride,
+                                  int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                                   void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
   int rc = attn_check("attention_bwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_bwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
   if (rc != GMLM_OK) return rc;
   if (b == 0 || (lq == 0 && lk == 0)) return GMLM_OK;
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_bwd: dropout_p must be in [0,1)");
@@ -660,17 +687,19 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   if ((rc = stride_check("attention_bwd(dk)", dk, dk_stride, h * d, dtype)) != GMLM_OK) return rc;
   if ((rc = stride_check("attention_bwd(dv)", dv, dv_stride, h * d, dtype)) != GMLM_OK) return rc;
   GMLM_REQUIRE(out && dout && lse && aligned16(out) && aligned16(dout), "attention_bwd: null or misaligned out/dout/lse");
-  GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_attention_bwd_workspace_bytes(b, h, lq, lk, d),
+  GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_attention_bwd_workspace_bytes(cu_seqlens ? 1 : b, h, lq, lk, d),
                "attention_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
   AttnParams p{};
-  p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = lse; p.kv_len = kv_len;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = lse; p.kv_len = kv_len; p.cu = cu_seqlens;
+  const int64_t rows_q = cu_seqlens ? max_len : lq, rows_k = cu_seqlens ? max_len : lk;
+  const int64_t nb = cu_seqlens ? 1 : b;        // delta kernel: packed tensors are one [total_rows, h, d] block
   p.delta = static_cast<float*>(workspace);
   p.dq = dq; p.dk = dk; p.dv = dv;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
   p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
-  const int64_t rows = b * lq * h;
+  const int64_t rows = nb * lq * h;
   {
     const int cpr = (int)d / (dtype == GMLM_BF16 ? 8 : 4);
     const int lanes = cpr <= 8 ? 8 : (cpr <= 16 ? 16 : 32);
@@ -681,19 +710,19 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
-  if (pick_waves(lq, b * h) == 4) {
-    dim3 gq((unsigned)cdiv(lq, 128), (unsigned)(b * h));
+  if (pick_waves(rows_q, b * h) == 4) {
+    dim3 gq((unsigned)cdiv(rows_q, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 4, gq, st, p);
   } else {
-    dim3 gq((unsigned)cdiv(lq, 64), (unsigned)(b * h));
+    dim3 gq((unsigned)cdiv(rows_q, 64), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 2, gq, st, p);
   }
   GMLM_LAUNCH_CHECK();
-  if (pick_waves(lk, b * h) == 4) {
-    dim3 gk((unsigned)cdiv(lk, 128), (unsigned)(b * h));
+  if (pick_waves(rows_k, b * h) == 4) {
+    dim3 gk((unsigned)cdiv(rows_k, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
   } else {
-    dim3 gk((unsigned)cdiv(lk, 64), (unsigned)(b * h));
+    dim3 gk((unsigned)cdiv(rows_k, 64), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
   }
   GMLM_LAUNCH_CHECK();

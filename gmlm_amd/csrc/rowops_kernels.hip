@@ -9,13 +9,13 @@ namespace gmlm {
 template <typename T>
 __global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__ hs, const int32_t* __restrict__ len,
                                                             const int64_t* __restrict__ node_idx, int64_t l, int64_t p,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, const int32_t* __restrict__ cu) {
   const int64_t b = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= p) return;
-  int n = len[b];
-  if (n > l) n = (int)l;
-  const T* base = hs + b * l * p + c;
+  int n = cu ? cu[b + 1] - cu[b] : len[b];
+  if (!cu && n > l) n = (int)l;
+  const T* base = hs + (cu ? (int64_t)cu[b] : b * l) * p + c;
   float acc = 0.f;
   for (int t = 0; t < n; ++t) acc += Store<T>::ld(base + (int64_t)t * p);
   out[node_idx[b] * p + c] = acc / fmaxf((float)n, 1e-9f);
@@ -24,15 +24,16 @@ __global__ __launch_bounds__(256) void meanpool_fwd_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void meanpool_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ len,
                                                             const int64_t* __restrict__ node_idx, int64_t l, int64_t p,
-                                                            T* __restrict__ dhs) {
+                                                            T* __restrict__ dhs, const int32_t* __restrict__ cu) {
   const int64_t b = blockIdx.y;
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= p) return;
-  int n = len[b];
-  if (n > l) n = (int)l;
+  int n = cu ? cu[b + 1] - cu[b] : len[b];
+  if (!cu && n > l) n = (int)l;
   const float g = dout[node_idx[b] * p + c] / fmaxf((float)n, 1e-9f);
-  T* base = dhs + b * l * p + c;
-  for (int64_t t = 0; t < l; ++t) Store<T>::st(base + t * p, t < n ? g : 0.f);
+  T* base = dhs + (cu ? (int64_t)cu[b] : b * l) * p + c;
+  const int64_t rows = cu ? n : l;
+  for (int64_t t = 0; t < rows; ++t) Store<T>::st(base + t * p, t < n ? g : 0.f);
 }
 
 template <typename T>
@@ -137,33 +138,34 @@ static inline dim3 stream_grid(int64_t rows, int64_t cols_units) {
 using namespace gmlm;
 
 extern "C" int gmlm_meanpool_scatter_fwd(const void* hs, const int32_t* len, const int64_t* node_idx, int64_t b, int64_t l,
-                                         int64_t p, float* out, int dtype, gmlm_stream_t stream) {
+                                         int64_t p, float* out, int dtype, const int32_t* cu_seqlens, gmlm_stream_t stream) {
   GMLM_REQUIRE(b >= 0 && l >= 0 && p > 0, "meanpool_scatter_fwd: bad sizes");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "meanpool_scatter_fwd: unsupported dtype");
   if (b == 0) return GMLM_OK;
-  GMLM_REQUIRE(len && node_idx && out && (hs || l == 0), "meanpool_scatter_fwd: null pointer");
+  GMLM_REQUIRE((len || cu_seqlens) && node_idx && out && (hs || l == 0), "meanpool_scatter_fwd: null pointer");
   GMLM_REQUIRE(b <= 65535, "meanpool_scatter_fwd: micro-batch %ld > 65535", (long)b);
   dim3 grid((unsigned)cdiv(p, 256), (unsigned)b);
   if (dtype == GMLM_F32)
-    meanpool_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)hs, len, node_idx, l, p, out);
+    meanpool_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>((const float*)hs, len, node_idx, l, p, out, cu_seqlens);
   else
-    meanpool_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)hs, len, node_idx, l, p, out);
+    meanpool_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>((const bf16_t*)hs, len, node_idx, l, p, out, cu_seqlens);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
 
 extern "C" int gmlm_meanpool_scatter_bwd(const float* dout, const int32_t* len, const int64_t* node_idx, int64_t b,
-                                         int64_t l, int64_t p, void* dhs, int dtype, gmlm_stream_t stream) {
+                                         int64_t l, int64_t p, void* dhs, int dtype, const int32_t* cu_seqlens,
+                                         gmlm_stream_t stream) {
   GMLM_REQUIRE(b >= 0 && l >= 0 && p > 0, "meanpool_scatter_bwd: bad sizes");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "meanpool_scatter_bwd: unsupported dtype");
-  if (b == 0 || l == 0) return GMLM_OK;
-  GMLM_REQUIRE(len && node_idx && dout && dhs, "meanpool_scatter_bwd: null pointer");
+  if (b == 0 || (l == 0 && !cu_seqlens)) return GMLM_OK;
+  GMLM_REQUIRE((len || cu_seqlens) && node_idx && dout && dhs, "meanpool_scatter_bwd: null pointer");
   GMLM_REQUIRE(b <= 65535, "meanpool_scatter_bwd: micro-batch %ld > 65535", (long)b);
   dim3 grid((unsigned)cdiv(p, 256), (unsigned)b);
   if (dtype == GMLM_F32)
-    meanpool_bwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (float*)dhs);
+    meanpool_bwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (float*)dhs, cu_seqlens);
   else
-    meanpool_bwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (bf16_t*)dhs);
+    meanpool_bwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(dout, len, node_idx, l, p, (bf16_t*)dhs, cu_seqlens);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }

@@ -91,6 +91,7 @@ class GraphTextLM(nn.Module):
         self.compute_dtype = compute_dtype
         self.activation_checkpointing = activation_checkpointing
         self.plm_gradient_checkpointing = plm_gradient_checkpointing
+        self.plm_packed = True        # variable-length token packing in the text encoder (head dim 64 / 96)
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
@@ -187,16 +188,33 @@ class GraphTextLM(nn.Module):
         lens_h = lens_h[order]
         idx = idx[order.to(dev)]
         grad = self.plm_encoder.training or self.training
+        heads = self.plm_encoder.config.num_attention_heads
+        packed = (p // heads) in (64, 96) and self.plm_packed
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
             weights = bert.prepare_weights(self.plm_encoder, cd)          # cast / fuse once, share across micro-batches
             for s in range(0, a, plm_batch_size):
                 bi = idx[s:s + plm_batch_size]
-                lmax = max(int(lens_h[s:s + plm_batch_size].max()), 1)   # host-side: no sync
-                ids = tokens.input_ids[bi, :lmax]
+                lh = lens_h[s:s + plm_batch_size]
+                lmax = max(int(lh.max()), 1)                              # host-side: no sync
                 lens = tokens.lens[bi]
-                hs = bert.bert_encode(self.plm_encoder, ids, lens, cd, self.plm_encoder.training,
-                                      self.plm_gradient_checkpointing, weights)
-                plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, lens, bi)
+                if packed:
+                    # variable-length packing: only real tokens exist; index arithmetic from the HOST copy of the
+                    # lengths (sizes known without a device sync), token gather on the device
+                    total = int(lh.sum())
+                    cu_h = torch.zeros(bi.numel() + 1, dtype=torch.int32)
+                    cu_h[1:] = torch.cumsum(lh, 0)
+                    cu = cu_h.to(dev, non_blocking=True)
+                    seq = torch.repeat_interleave(torch.arange(bi.numel(), device=dev), lens.long(), output_size=total)
+                    pos = torch.arange(total, device=dev) - cu[seq].long()
+                    tok = tokens.input_ids[bi[seq], pos]
+                    hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu, lmax, cd, self.plm_encoder.training,
+                                                 self.plm_gradient_checkpointing, weights)
+                    plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, None, bi, cu)
+                else:
+                    ids = tokens.input_ids[bi, :lmax]
+                    hs = bert.bert_encode(self.plm_encoder, ids, lens, cd, self.plm_encoder.training,
+                                          self.plm_gradient_checkpointing, weights)
+                    plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, lens, bi)
         return plm_embeds
 
     def forward(self, gnn_input_features, edge_index, all_node_texts, text_processing_node_mask, edge_type=None,

@@ -359,7 +359,7 @@ class Attention(torch.autograd.Function):
         lse = torch.empty(b, h, lq, dtype=torch.float32, device=q.device)
         with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * lq * lk * d):
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
-                                           float(p), seed, _ptr(out), _ptr(lse), _dt(q), _stream()), "gmlm_attention_fwd")
+                                           float(p), seed, _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
         ctx.save_for_backward(q, k, v, out, lse, kv_len)
         ctx.cfg = (h, float(scale), float(p), seed)
         return out
@@ -380,55 +380,68 @@ class Attention(torch.autograd.Function):
         with _span("attn_bwd_d%d" % d, flops=10.0 * b * h * lq * lk * d):
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, _ptr(dq),
-                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), _ptr(ws), ws.numel(), _stream()),
+                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), _stream()),
                   "gmlm_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
 
 
 class AttentionQKV(torch.autograd.Function):
-    """Self-attention on a fused [b, l, 3*h*d] QKV buffer (BERT layout).  Forward reads q/k/v in place
-    through row strides; backward writes dq|dk|dv straight into ONE [b, l, 3*h*d] gradient buffer, so no
-    slice-gradient accumulation passes are needed."""
+    """Self-attention on a fused QKV buffer (BERT layout).  Forward reads q/k/v in place through row
+    strides; backward writes dq|dk|dv straight into ONE gradient buffer of the same layout, so no
+    slice-gradient accumulation passes are needed.
+
+    padded mode: qkv [b, l, 3*h*d], kv_len int32 [b] or None.
+    packed mode: qkv [total_rows, 3*h*d], cu_seqlens int32 [b+1], max_len = longest sequence: sequence i owns
+    rows [cu[i], cu[i+1]) and attends only to itself; no padded token exists anywhere.
+    """
 
     @staticmethod
-    def forward(ctx, qkv, kv_len, h, scale, p, seed):
+    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len):
         _cuda(qkv)
         qkv = qkv.contiguous()
-        b, l, hd3 = qkv.shape
+        packed = cu_seqlens is not None
+        if packed:
+            l, hd3 = qkv.shape
+            b = cu_seqlens.numel() - 1
+        else:
+            b, l, hd3 = qkv.shape
         hd = hd3 // 3
         d = hd // h
         q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
-        out = torch.empty(b, l, hd, dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty(b, h, l, dtype=torch.float32, device=qkv.device)
-        with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * l * l * d):
+        out = torch.empty(qkv.shape[:-1] + (hd,), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((h, l) if packed else (b, h, l), dtype=torch.float32, device=qkv.device)
+        flops = 4.0 * h * d * (float(max_len) * l if packed else float(b) * l * l)     # packed: upper bound max_len * rows
+        with _span("attn_fwd_d%d" % d, flops=flops):
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
-                                           float(p), seed, _ptr(out), _ptr(lse), _dt(qkv), _stream()), "gmlm_attention_fwd")
-        ctx.save_for_backward(qkv, out, lse, kv_len)
-        ctx.cfg = (h, float(scale), float(p), seed)
+                                           float(p), seed, _ptr(out), _ptr(lse), _dt(qkv), _ptr(cu_seqlens), int(max_len),
+                                           _stream()), "gmlm_attention_fwd")
+        ctx.save_for_backward(qkv, out, lse, kv_len, cu_seqlens)
+        ctx.cfg = (h, float(scale), float(p), seed, int(max_len), b, l, flops)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        qkv, out, lse, kv_len = ctx.saved_tensors
-        h, scale, p, seed = ctx.cfg
-        b, l, hd3 = qkv.shape
+        qkv, out, lse, kv_len, cu_seqlens = ctx.saved_tensors
+        h, scale, p, seed, max_len, b, l, flops = ctx.cfg
+        hd3 = qkv.shape[-1]
         hd = hd3 // 3
         d = hd // h
         gout = gout.contiguous().to(qkv.dtype)
         q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = dqkv[..., :hd], dqkv[..., hd:2 * hd], dqkv[..., 2 * hd:]
-        ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, h, l, l, d), qkv.device)
-        with _span("attn_bwd_d%d" % d, flops=10.0 * b * h * l * l * d):
+        ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(1 if cu_seqlens is not None else b, h, l, l, d), qkv.device)
+        with _span("attn_bwd_d%d" % d, flops=2.5 * flops):
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            l, l, d, hd3, hd3, hd3, scale, p, seed, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
-                                           hd3, _dt(qkv), _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
-        return dqkv, None, None, None, None, None
+                                           hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _stream()),
+                  "gmlm_attention_bwd")
+        return dqkv, None, None, None, None, None, None, None
 
 
-def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False):
+def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0):
     p = float(dropout_p) if training else 0.0
-    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0)
+    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len)
 
 
 def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
@@ -440,31 +453,35 @@ def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
 # K8: masked mean pool + row scatter
 # ---------------------------------------------------------------------------------------------
 class MeanPoolScatter(torch.autograd.Function):
-    """plm_embeds[node_idx[b]] = sum_t hs[b,t]*[t<len[b]] / max(len[b],1e-9)  (main.py:351-358), in place."""
+    """plm_embeds[node_idx[b]] = sum_t hs[b,t]*[t<len[b]] / max(len[b],1e-9)  (main.py:351-358), in place.
+    hs is [b, l, p] (padded, ``lens``) or [total_rows, p] (packed, ``cu_seqlens``)."""
 
     @staticmethod
-    def forward(ctx, plm_embeds, hs, lens, node_idx):
+    def forward(ctx, plm_embeds, hs, lens, node_idx, cu_seqlens=None):
         _cuda(hs, plm_embeds)
         hs = hs.contiguous()
-        b, l, p = hs.shape
+        if cu_seqlens is not None:
+            b, l, p = cu_seqlens.numel() - 1, 0, hs.shape[-1]
+        else:
+            b, l, p = hs.shape
         check(lib().gmlm_meanpool_scatter_fwd(_ptr(hs), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(plm_embeds), _dt(hs),
-                                              _stream()), "gmlm_meanpool_scatter_fwd")
+                                              _ptr(cu_seqlens), _stream()), "gmlm_meanpool_scatter_fwd")
         ctx.mark_dirty(plm_embeds)
-        ctx.save_for_backward(lens, node_idx)
-        ctx.cfg = (b, l, p, hs.dtype)
+        ctx.save_for_backward(lens, node_idx, cu_seqlens)
+        ctx.cfg = (b, l, p, hs.dtype, tuple(hs.shape))
         return plm_embeds
 
     @staticmethod
     def backward(ctx, g):
-        lens, node_idx = ctx.saved_tensors
-        b, l, p, dtype = ctx.cfg
+        lens, node_idx, cu_seqlens = ctx.saved_tensors
+        b, l, p, dtype, shape = ctx.cfg
         g = g.contiguous().float()
-        dhs = torch.empty(b, l, p, dtype=dtype, device=g.device)
-        check(lib().gmlm_meanpool_scatter_bwd(_ptr(g), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(dhs), _dt(dhs), _stream()),
-              "gmlm_meanpool_scatter_bwd")
+        dhs = torch.empty(shape, dtype=dtype, device=g.device)
+        check(lib().gmlm_meanpool_scatter_bwd(_ptr(g), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(dhs), _dt(dhs),
+                                              _ptr(cu_seqlens), _stream()), "gmlm_meanpool_scatter_bwd")
         # rows written by this micro-batch were overwritten: no gradient flows to their previous value;
         # the previous value is the zero-initialised buffer (a constant), so passing g through is harmless.
-        return g, dhs, None, None
+        return g, dhs, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------

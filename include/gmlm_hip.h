@@ -178,6 +178,10 @@ int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias
  * kv_len: int32 [b] valid key count per sequence (NULL = all lk keys valid); keys >= kv_len[b]
  * are masked out exactly like the additive -inf padding mask of create_bidirectional_mask.
  * d in {64, 96}.  MFMA: bf16 32x32x16 for GMLM_BF16, f32 32x32x2 for GMLM_F32.
+ * Packed (variable-length) mode: cu_seqlens int32 [b+1] != NULL.  q, k, v, out are then [total_rows, h*d]
+ * row blocks with sequence i owning rows [cu[i], cu[i+1]) of ALL of them (self-attention), lq = lk =
+ * total_rows, max_len = longest sequence, kv_len = NULL, lse is [h, total_rows].  No padded token is ever
+ * computed: this is how the text encoder runs (one packed batch of all active nodes).
  * dropout_p > 0 drops attention probabilities (after normalisation, scaled by 1/(1-p)) exactly like
  * nn.Dropout on `attn` in main.py:161 / hf eager attention; the mask is hash(seed, (b,h,q,key)) and
  * is regenerated, not stored, by the backward pass when given the same seed.
@@ -185,22 +189,26 @@ int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias
 int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                        int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
                        float scale, float dropout_p, uint64_t seed, void* out, float* lse, int dtype,
-                       gmlm_stream_t stream);
+                       const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream);
+/* packed mode: pass b = 1 (delta is [h, total_rows]) */
 size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d);
 int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                        const float* lse, const int32_t* kv_len, int64_t b, int64_t h, int64_t lq, int64_t lk,
                        int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
-                       float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, int dtype,
+                       float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride,
+                       int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                        void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  attention-mask-weighted mean pooling + row scatter          (main.py:351-358)
  * out[node_idx[b], :] = sum_t hs[b,t,:] * [t < len[b]] / max(len[b], 1e-9)     (out fp32 [n, p])
- * ------------------------------------------------------------------------------------------- */
+ * -------------------------------------------------------------------------------------------
+ * cu_seqlens != NULL: hs is packed [total_rows, p], sequence b = rows [cu[b], cu[b+1]) (len / l unused).
+ */
 int gmlm_meanpool_scatter_fwd(const void* hs, const int32_t* len, const int64_t* node_idx, int64_t b, int64_t l,
-                              int64_t p, float* out, int dtype, gmlm_stream_t stream);
+                              int64_t p, float* out, int dtype, const int32_t* cu_seqlens, gmlm_stream_t stream);
 int gmlm_meanpool_scatter_bwd(const float* dout, const int32_t* len, const int64_t* node_idx, int64_t b, int64_t l,
-                              int64_t p, void* dhs, int dtype, gmlm_stream_t stream);
+                              int64_t p, void* dhs, int dtype, const int32_t* cu_seqlens, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9  soft-mask row blend                                           (main.py:92-99)

@@ -446,3 +446,30 @@ def test_basis_compose_fwd_bwd(dev, ra, nb, cols):
     np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-5, atol=1e-5)
     sc = float(cr.grad.abs().max())
     np.testing.assert_allclose(cd_.grad.cpu().numpy(), cr.grad.numpy(), rtol=1e-4, atol=1e-5 * sc)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_packed_varlen_matches_padded(dev, dt):
+    """Packed (cu_seqlens) self-attention == padded attention with key lengths, forward and backward, incl.
+    sequences of length 1, exactly one tile and many tiles."""
+    from gmlm_amd.ops import attention_qkv
+    h, d = 12, 64
+    lens = torch.tensor([1, 64, 130, 7, 128, 300, 65])
+    b, lmax, tot = lens.numel(), int(lens.max()), int(lens.sum())
+    g = torch.Generator().manual_seed(12)
+    qkv_pad = torch.randn(b, lmax, 3 * h * d, generator=g).to(dt)
+    go_pad = torch.randn(b, lmax, h * d, generator=g).to(dt)
+    valid = torch.arange(lmax)[None] < lens[:, None]
+    cu = torch.zeros(b + 1, dtype=torch.int32)
+    cu[1:] = torch.cumsum(lens, 0)
+    qp = qkv_pad.to(dev).requires_grad_(True)
+    yp = attention_qkv(qp, lens.to(dev, torch.int32), h, d ** -0.5)
+    (yp * go_pad.to(dev) * valid.to(dev)[..., None]).sum().backward()
+    qk = qkv_pad[valid].to(dev).requires_grad_(True)                 # [tot, 3hd]
+    yk = attention_qkv(qk, None, h, d ** -0.5, 0.0, False, cu.to(dev), lmax)
+    (yk * go_pad[valid].to(dev)).sum().backward()
+    assert yk.shape == (tot, h * d)
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    np.testing.assert_allclose(yk.float().detach().cpu().numpy(), yp.float().detach().cpu()[valid].numpy(), rtol=tol, atol=tol)
+    gsc = float(qp.grad.float().abs().max())
+    np.testing.assert_allclose(qk.grad.float().cpu().numpy(), qp.grad.float().cpu()[valid].numpy(), rtol=10 * tol, atol=2 * tol * gsc)

@@ -269,3 +269,30 @@ def test_text_list_drop_in_path(dev):
                    plm_batch_size=cfg["plm_batch_size"])
     np.testing.assert_allclose(logits.cpu().numpy(), g["logits"], rtol=0, atol=1e-4)
     assert m.tokenize(texts) is tt                                                       # cached by list identity
+
+
+def test_packed_bert_matches_hf_golden(dev):
+    """Variable-length (packed) encoder pass vs HF BertModel outputs of the golden fixture (BERT-base geometry)."""
+    from gmlm_amd import bert, ops
+    g = load_golden("g4_bert_base")
+    c = g["config"]
+    plm = hf_bert(dict(vocab=c["vocab"], hidden=c["hidden"], layers=c["layers"], heads=c["heads"], inter=c["inter"],
+                       max_pos=c["max_pos"]))
+    plm.load_state_dict(recipe_state_dict(bert_state_template(c["hidden"], c["layers"], c["inter"], c["vocab"], c["max_pos"]),
+                                          c["seed"]))
+    plm = plm.to(dev).train()
+    ids, am = t(g["input_ids"]).to(dev), t(g["attention_mask"]).to(dev).bool()
+    lens = am.sum(-1)
+    b, l = ids.shape
+    cu = torch.zeros(b + 1, dtype=torch.int32, device=dev)
+    cu[1:] = torch.cumsum(lens, 0)
+    pos = torch.arange(l, device=dev)[None].expand(b, l)[am]
+    hs = bert.bert_encode_packed(plm, ids[am], pos, cu, int(lens.max()), torch.float32, training=True)
+    np.testing.assert_allclose(hs.detach().cpu().numpy(), t(g["last_hidden_state"])[am.cpu()].numpy(), rtol=1e-4, atol=1e-4)
+    pooled = ops.MeanPoolScatter.apply(torch.zeros(b, c["hidden"], device=dev), hs, None, torch.arange(b, device=dev), cu)
+    np.testing.assert_allclose(pooled.detach().cpu().numpy(), g["pooled"], rtol=1e-4, atol=5e-5)
+    (pooled * t(g["grad_pooled"]).to(dev)).sum().backward()
+    grads = {k: v.grad for k, v in plm.named_parameters()}
+    for k, ref in g["grad_norms"].items():
+        nrm = float(grads[k].double().norm())
+        assert abs(nrm - ref) <= 2e-3 * max(ref, 1e-3) + 1e-6, (k, nrm, ref)
