@@ -112,13 +112,13 @@ def _mm(x, w, b=None):
         return _Linear.apply(x, w, b)
 
 
-def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0):
+def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None):
     pdim = h.shape[-1]
     d = pdim // heads
     qkv = _mm(h, lw.wqkv, lw.bqkv)                                                  # [B, L, 3P] or packed [T, 3P]
     scale = d ** -0.5
     if d in (64, 96):
-        ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len)
+        ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len, pair_count)
     else:
         ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
                                 training)
@@ -156,7 +156,8 @@ def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtyp
 
 
 def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
-                       cd: torch.dtype, training: bool = False, gradient_checkpointing: bool = False, weights=None):
+                       cd: torch.dtype, training: bool = False, gradient_checkpointing: bool = False, weights=None,
+                       pair_count=None):
     """Variable-length (packed) encoder pass: ``token_ids`` int [T] = the valid tokens of all sequences back to
     back, ``pos_ids`` int [T] = position of each token inside its sequence, ``cu_seqlens`` int32 [B+1].
     Returns [T, P].  Every GEMM / LayerNorm / GELU row is a real token and attention never sees padding
@@ -175,9 +176,10 @@ def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_s
         weights = prepare_weights(plm, cd)
     for lw in weights:
         if gradient_checkpointing and training and torch.is_grad_enabled():
-            h = checkpoint(_layer, lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, use_reentrant=False)
+            h = checkpoint(_layer, lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count,
+                           use_reentrant=False)
         else:
-            h = _layer(lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len)
+            h = _layer(lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count)
     return h
 
 

@@ -208,7 +208,8 @@ class GraphTextLM(nn.Module):
                     pos = torch.arange(total, device=dev) - cu[seq].long()
                     tok = tokens.input_ids[bi[seq], pos]
                     hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu, lmax, cd, self.plm_encoder.training,
-                                                 self.plm_gradient_checkpointing, weights)
+                                                 self.plm_gradient_checkpointing, weights,
+                                                 pair_count=float((lh.double() ** 2).sum()))
                     plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, None, bi, cu)
                 else:
                     ids = tokens.input_ids[bi, :lmax]

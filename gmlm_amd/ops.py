@@ -396,7 +396,7 @@ class AttentionQKV(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len):
+    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len, pair_count=None):
         _cuda(qkv)
         qkv = qkv.contiguous()
         packed = cu_seqlens is not None
@@ -410,7 +410,8 @@ class AttentionQKV(torch.autograd.Function):
         q, k, v = qkv[..., :hd], qkv[..., hd:2 * hd], qkv[..., 2 * hd:]
         out = torch.empty(qkv.shape[:-1] + (hd,), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((h, l) if packed else (b, h, l), dtype=torch.float32, device=qkv.device)
-        flops = 4.0 * h * d * (float(max_len) * l if packed else float(b) * l * l)     # packed: upper bound max_len * rows
+        # packed: exact sum of len^2 when the caller knows it (host copy of the lengths), else the bound max_len * rows
+        flops = 4.0 * h * d * ((float(pair_count) if pair_count else float(max_len) * l) if packed else float(b) * l * l)
         with _span("attn_fwd_d%d" % d, flops=flops):
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
                                            float(p), seed, _ptr(out), _ptr(lse), _dt(qkv), _ptr(cu_seqlens), int(max_len),
@@ -436,12 +437,12 @@ class AttentionQKV(torch.autograd.Function):
                                            l, l, d, hd3, hd3, hd3, scale, p, seed, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
                                            hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _stream()),
                   "gmlm_attention_bwd")
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
-def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0):
+def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0, pair_count=None):
     p = float(dropout_p) if training else 0.0
-    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len)
+    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len, pair_count)
 
 
 def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
