@@ -181,22 +181,33 @@ struct TileRegs {
   static constexpr int V = Store<T>::kVec, CPR = D / V, TOTAL = ROWS * CPR, PER = (TOTAL + NT - 1) / NT,
                        PITCH = D + Pad<T>::v;
   uint4 v[PER];
-  __device__ __forceinline__ void load(const T* g, int64_t g_stride, int64_t row0, int64_t limit, int tid) {
+  int goff[PER];   // element offset of this thread's k-th chunk inside a tile (row * g_stride + col), computed once
+  int loff[PER];   // LDS element offset
+  int rowk[PER];   // tile row of the chunk (bounds check against the rows left)
+  __device__ __forceinline__ void init(int64_t g_stride, int tid) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + k * NT;
       const int row = i / CPR, c = i % CPR;
-      v[k] = make_uint4(0, 0, 0, 0);
-      if (i < TOTAL && row0 + row < limit) v[k] = *reinterpret_cast<const uint4*>(g + (row0 + row) * g_stride + c * V);
+      rowk[k] = i < TOTAL ? row : (1 << 30);
+      goff[k] = (int)(row * g_stride) + c * V;
+      loff[k] = row * PITCH + c * V;
     }
   }
-  __device__ __forceinline__ void store(T* ts, int tid) const {
+  // g: start of the (batch, head) slab; row0: first row of the tile (block-uniform); limit: rows in the slab
+  __device__ __forceinline__ void load(const T* g, int64_t g_stride, int64_t row0, int64_t limit, int /*tid*/) {
+    const T* base = g + row0 * g_stride;          // wave-uniform
+    const int left = (int)(limit - row0 < (1 << 29) ? limit - row0 : (1 << 29));
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int i = tid + k * NT;
-      const int row = i / CPR, c = i % CPR;
-      if (i < TOTAL) *reinterpret_cast<uint4*>(ts + row * PITCH + c * V) = v[k];
+      v[k] = make_uint4(0, 0, 0, 0);
+      if (rowk[k] < left) v[k] = *reinterpret_cast<const uint4*>(base + goff[k]);
     }
+  }
+  __device__ __forceinline__ void store(T* ts, int /*tid*/) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k)
+      if (rowk[k] < ROWS) *reinterpret_cast<uint4*>(ts + loff[k]) = v[k];
   }
 };
 
@@ -253,6 +264,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   const int ntiles = (int)((kvlen + KT - 1) / KT);
   TileRegs<T, D, KT, NT> kr, vr;
+  kr.init(p.k_stride, tid);
+  vr.init(p.v_stride, tid);
   if (ntiles > 0) {
     kr.load(kg, p.k_stride, 0, lk_, tid);
     vr.load(vg, p.v_stride, 0, lk_, tid);
@@ -418,6 +431,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
     for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
   const int ntiles = (int)((kvlen + KT - 1) / KT);
   TileRegs<T, D, KT, NT> kr, vr;
+  kr.init(p.k_stride, tid);
+  vr.init(p.v_stride, tid);
   if (ntiles > 0) {
     kr.load(kg, p.k_stride, 0, lk_, tid);
     vr.load(vg, p.v_stride, 0, lk_, tid);
@@ -514,6 +529,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   if (block_live) {
     const int ntiles = (int)((lq_ + QT - 1) / QT);
     TileRegs<T, D, QT, NT> qr, dor;
+    qr.init(p.q_stride, tid);
+    dor.init(p.h * D, tid);
     float lr = 0.f, dr = 0.f;
     auto load_small = [&](int64_t q0) {
       if (tid < QT) {
@@ -601,8 +618,8 @@ static int attn_check(const char* who, int64_t b, int64_t h, int64_t lq, int64_t
 static int stride_check(const char* who, const void* ptr, int64_t stride, int64_t min_stride, int dtype) {
   const int v = dtype == GMLM_F32 ? 4 : 8;
   GMLM_REQUIRE(ptr && aligned16(ptr), "%s: null or not 16-byte aligned pointer", who);
-  GMLM_REQUIRE(stride >= min_stride && stride % v == 0, "%s: row stride %ld must be >= %ld and a multiple of %d", who,
-               (long)stride, (long)min_stride, v);
+  GMLM_REQUIRE(stride >= min_stride && stride % v == 0 && stride < (1 << 24),
+               "%s: row stride %ld must be >= %ld, < 2^24 and a multiple of %d", who, (long)stride, (long)min_stride, v);
   return GMLM_OK;
 }
 
