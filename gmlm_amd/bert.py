@@ -72,7 +72,8 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     s = 1
     if tiles < 128 and t >= 4096:
         import math
-        s = min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
+        # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
+        s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
         while s > 1 and t % s:
             s //= 2
     if s == 1:

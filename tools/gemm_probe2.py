@@ -1,0 +1,20 @@
+"""Probe: split-K wgrad orientation at the packed token count."""
+import torch, time
+dev = torch.device("cuda")
+def t(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+T = 90496
+for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
+    x = torch.randn(T, K, device=dev, dtype=torch.bfloat16); dy = torch.randn(T, N, device=dev, dtype=torch.bfloat16)
+    fl = 2.0 * T * N * K
+    line = f"N={N} K={K}:"
+    for S in (4, 8, 16, 32):
+        if T % S: continue
+        a = t(lambda: torch.bmm(dy.view(S, T // S, N).transpose(1, 2), x.view(S, T // S, K), out_dtype=torch.float32).sum(0))
+        b = t(lambda: torch.bmm(x.view(S, T // S, K).transpose(1, 2), dy.view(S, T // S, N), out_dtype=torch.float32).sum(0))
+        c = t(lambda: torch.bmm(dy.view(S, T // S, N).transpose(1, 2), x.view(S, T // S, K)).float().sum(0))
+        line += f" S={S}: dyT@x {a:.3f} ({fl/a/1e9:.0f}TF) xT@dy {b:.3f} ({fl/b/1e9:.0f}TF) bf16out {c:.3f} |"
+    print(line, flush=True)
