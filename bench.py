@@ -128,7 +128,15 @@ def cpu_baseline(args, data, ids, am):
     t_plm = time.time() - t1
     say(f"BERT leg on {sample.numel()} nodes done ({t_plm:.1f}s)")
     est = t_rest + t_plm * (idx.numel() / max(sample.numel(), 1))
+    # the reference's per-edge Python loop for edge typing (main.py:257-267), timed on a bounded sample of edges and
+    # scaled linearly: the "faithful" variant of SURVEY.md section 8d
+    t2 = time.time()
+    ne = min(data["e"], 20000)
+    O.edge_types_loop(data["edge_index"][:, :ne], data["n"])
+    t_loop = (time.time() - t2) * (data["e"] / ne)
+    say(f"per-edge typing loop: {t_loop:.1f}s for all edges (scaled from {ne})")
     return dict(value=round(data["n"] / est, 3), unit="nodes/s", cores=threads, kind="port",
+                faithful_value=round(data["n"] / (est + t_loop), 3),
                 sample=(f"oracle (CPU fp32 restatement) fwd+bwd on the same {data['n']}-node graph, vectorised edge typing, "
                         f"hidden_channels={hc}{'' if hc == args.hc else ' (bench uses %d)' % args.hc}: GNN + cross-attention + head "
                         f"on the full graph measured ({t_rest:.1f}s); BERT leg measured on {sample.numel()} of {idx.numel()} "
