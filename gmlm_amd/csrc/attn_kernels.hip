@@ -198,10 +198,15 @@ struct TileRegs {
   __device__ __forceinline__ void load(const T* g, int64_t g_stride, int64_t row0, int64_t limit, int /*tid*/) {
     const T* base = g + row0 * g_stride;          // wave-uniform
     const int left = (int)(limit - row0 < (1 << 29) ? limit - row0 : (1 << 29));
+    if (left >= ROWS && TOTAL % NT == 0) {        // interior tile (block-uniform): no bounds checks, no zero fill
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      v[k] = make_uint4(0, 0, 0, 0);
-      if (rowk[k] < left) v[k] = *reinterpret_cast<const uint4*>(base + goff[k]);
+      for (int k = 0; k < PER; ++k) v[k] = *reinterpret_cast<const uint4*>(base + goff[k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        if (rowk[k] < left) v[k] = *reinterpret_cast<const uint4*>(base + goff[k]);
+        else v[k] = make_uint4(0, 0, 0, 0);
+      }
     }
   }
   __device__ __forceinline__ void store(T* ts, int /*tid*/) const {
@@ -223,6 +228,18 @@ __device__ __forceinline__ uint32_t drop_word(uint32_t seed, uint32_t qmix, uint
 }
 __device__ __forceinline__ float drop_mul16(uint32_t word, int half, uint32_t th16, float ks) {
   return ((word >> (16 * half)) & 0xFFFFu) >= th16 ? ks : 0.f;
+}
+
+// exchange between the two 32-lane halves of the wave on the VALU (v_permlane32_swap) instead of an LDS
+// bpermute: r[0] / r[1] hold {own, other-half} values in some order for every lane, so max / sum of the
+// pair need no select
+__device__ __forceinline__ float xhalf_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 constexpr float kLog2e = 1.4426950408889634f;
@@ -305,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
           rmax = fmaxf(rmax, v);
         }
     }
-    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    rmax = xhalf_max(rmax);
     // deferred rescale: keep the old reference max while the new one exceeds it by < 2^kDefer (probabilities
     // then stay <= 2^kDefer, harmless in fp32 / bf16); the O and l rescale is skipped for the whole wave then
     float m_new = fmaxf(m, rmax * sl2);             // finite: key kv0 is always valid
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
           s[kb][i + 1] = e1;
         }
       }
-    rsum += __shfl_xor(rsum, 32, 64);
+    rsum = xhalf_sum(rsum);
     l = l * alpha + rsum;
     m = m_new;
     if (!keep) {
@@ -643,8 +660,14 @@ using namespace gmlm;
     else GMLM_ATTN_DISPATCH2(KERNEL, NWV, false, grid, st, prm);                             \
   } while (0)
 
-// 4 waves (128 rows) per workgroup unless that leaves the 256 CUs under-filled: then 2 waves (64 rows)
-static inline int pick_waves(int64_t rows, int64_t bh) { return cdiv(rows, 128) * bh >= 1024 ? 4 : 2; }
+// Rows per workgroup.  Every workgroup streams ALL keys of its (batch, head) through LDS, so the K/V bytes read
+// per flop fall with the number of query rows that share a tile: 8 waves = 256 rows for long sequences when there
+// are enough workgroups to fill the chip twice (measured: forward neutral, backward +4 % at N = 20k); 4 waves
+// (128 rows) by default; 2 waves (64 rows) when the grid would under-fill the 256 CUs (+80 % at N = 5k).
+static inline int pick_waves(int64_t rows, int64_t bh) {
+  if (rows >= 2048 && cdiv(rows, 256) * bh >= 512) return 8;
+  return cdiv(rows, 128) * bh >= 1024 ? 4 : 2;
+}
 
 extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                                   int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
@@ -669,7 +692,10 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   p.scale = scale;
   p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
   hipStream_t st = as_stream(stream);
-  if (pick_waves(rows_q, b * h) == 4) {
+  if (pick_waves(rows_q, b * h) == 8) {
+    dim3 grid((unsigned)cdiv(rows_q, 256), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_fwd_kernel, 8, grid, st, p);
+  } else if (pick_waves(rows_q, b * h) == 4) {
     dim3 grid((unsigned)cdiv(rows_q, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_fwd_kernel, 4, grid, st, p);
   } else {
@@ -727,7 +753,10 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
-  if (pick_waves(rows_q, b * h) == 4) {
+  if (pick_waves(rows_q, b * h) == 8) {
+    dim3 gq((unsigned)cdiv(rows_q, 256), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 8, gq, st, p);
+  } else if (pick_waves(rows_q, b * h) == 4) {
     dim3 gq((unsigned)cdiv(rows_q, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 4, gq, st, p);
   } else {
@@ -735,7 +764,10 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 2, gq, st, p);
   }
   GMLM_LAUNCH_CHECK();
-  if (pick_waves(rows_k, b * h) == 4) {
+  if (pick_waves(rows_k, b * h) == 8) {
+    dim3 gk((unsigned)cdiv(rows_k, 256), (unsigned)(b * h));
+    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 8, gk, st, p);
+  } else if (pick_waves(rows_k, b * h) == 4) {
     dim3 gk((unsigned)cdiv(rows_k, 128), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
   } else {
