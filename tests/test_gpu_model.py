@@ -296,3 +296,36 @@ def test_packed_bert_matches_hf_golden(dev):
     for k, ref in g["grad_norms"].items():
         nrm = float(grads[k].double().norm())
         assert abs(nrm - ref) <= 2e-3 * max(ref, 1e-3) + 1e-6, (k, nrm, ref)
+
+
+def test_activation_checkpointing_replays_dropout(dev):
+    """Reference-style activation checkpointing (main.py:278-314) with dropout ON: the recompute must draw the
+    same dropout masks as the first forward (seeds come from torch's CPU generator, whose state the checkpoint
+    restores), so gradients equal those of the non-checkpointed run with the same seed."""
+    plm = dict(hidden=128, layers=1, heads=2, inter=256, max_pos=64, vocab=200)
+    n, e = 400, 3000
+    cfg = dict(n=n, e=e, f_in=40, hc=32, c=4, plm=plm, seed=13)
+    g = torch.Generator().manual_seed(4)
+    x, ei = torch.randn(n, 40, generator=g).to(dev), torch.randint(0, n, (2, e), generator=g).to(dev)
+    go = torch.randn(n, 128, generator=g).to(dev)
+    grads = []
+    for ckpt in (False, True):
+        m = build_model(cfg, dev).train()
+        for k in range(1, 5):
+            getattr(m, f"dropout{k}").p = 0.3
+        m.activation_checkpointing = ckpt
+        torch.manual_seed(1234)
+        out = m.get_graph_embeddings(x, ei)
+        out.backward(go)
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 20
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * (1 + float(a.abs().max()))), k
+    # and dropout really was active: a different seed gives different gradients
+    m = build_model(cfg, dev).train()
+    for k in range(1, 5):
+        getattr(m, f"dropout{k}").p = 0.3
+    torch.manual_seed(99)
+    m.get_graph_embeddings(x, ei).backward(go)
+    assert not torch.allclose(m.rgcn1.root.grad, grads[0]["rgcn1.root"], rtol=1e-3, atol=1e-6)
