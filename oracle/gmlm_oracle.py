@@ -401,3 +401,13 @@ def synthetic_tokens(n: int, max_len: int, vocab: int, seed: int, min_len: int =
     ids = torch.randint(5, vocab, (n, max_len), generator=g)
     am = (torch.arange(max_len)[None, :] < lens[:, None]).long()
     return ids * am, am
+
+
+def split_plan(rowptr: np.ndarray, thresh: int):
+    """Numpy restatement of gmlm_amd.graph.make_split_plan (chunking of long CSR segments): checker only."""
+    lens = np.diff(rowptr.astype(np.int64))
+    long_seg = np.nonzero(lens > thresh)[0]
+    nch = (lens[long_seg] + thresh - 1) // thresh
+    chunk_ptr = np.concatenate([[0], np.cumsum(nch)])
+    owner = np.repeat(np.arange(long_seg.size), nch)
+    return long_seg.astype(np.int32), chunk_ptr.astype(np.int32), owner.astype(np.int32)

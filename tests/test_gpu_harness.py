@@ -108,3 +108,39 @@ def test_pretrain_step_nt_xent():
     assert abs(l0 - ref) < 1e-4
     l1 = harness.pretrain_step(m, opt, x, ei, m1, m2, autocast=False)
     assert np.isfinite(l1) and l1 < l0            # same views, one optimiser step: the contrastive loss drops
+
+
+def test_bf16_training_reduces_loss_on_learnable_labels():
+    """End-to-end sanity of the bf16 training path (autocast, dropout ON, AdamW, clip, warm-up): labels are a
+    function of the node features, so a few dozen full-batch steps must cut the training loss."""
+    import gmlm_amd
+    from gmlm_amd import harness
+    from transformers import BertConfig, BertModel
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    n, e, f_in, c = 600, 4000, 64, 4
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, f_in, generator=g)
+    proto = torch.randn(c, f_in, generator=g)
+    y = (x @ proto.t()).argmax(1)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ids, am = O.synthetic_tokens(n, 16, 200, 3, 4)
+    ids[:, 1] = 5 + y                                   # the text carries the label too
+    enc = BertModel(BertConfig(vocab_size=200, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                               intermediate_size=256, max_position_embeddings=64))
+    m = gmlm_amd.GraphTextLM(f_in, 32, c, dropout_rate=0.1, plm_encoder=enc).to(dev)
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    train = torch.zeros(n, dtype=torch.bool)
+    train[: n // 2] = True
+    xd, eid, yd, td = x.to(dev), ei.to(dev), y.to(dev), train.to(dev)
+    opt = harness.setup_optimizer(m, 3e-3, 3e-4, 3e-3, 0.01)
+    sched = harness.linear_warmup_schedule(opt, 3, 60)
+    losses = []
+    for step in range(40):
+        mk = harness.generate_active_node_mask(xd, eid, 0.6, td)
+        r = harness.train_step(m, opt, sched, xd, eid, tokens, yd, mk, plm_batch_size=4096, autocast=True)
+        assert not r.skipped and np.isfinite(r.loss)
+        losses.append(r.loss)
+    assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
+    loss, acc, f1 = harness.eval_step(m, xd, eid, tokens, yd, ~td, plm_batch_size=4096)
+    assert np.isfinite(loss) and acc > 1.0 / c

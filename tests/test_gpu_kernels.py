@@ -473,3 +473,20 @@ def test_attention_packed_varlen_matches_padded(dev, dt):
     np.testing.assert_allclose(yk.float().detach().cpu().numpy(), yp.float().detach().cpu()[valid].numpy(), rtol=tol, atol=tol)
     gsc = float(qp.grad.float().abs().max())
     np.testing.assert_allclose(qk.grad.float().cpu().numpy(), qp.grad.float().cpu()[valid].numpy(), rtol=10 * tol, atol=2 * tol * gsc)
+
+
+def test_split_plan_index_arrays_bit_exact(dev):
+    """The long-segment chunk tables (index data of K2/K3) equal the numpy restatement exactly."""
+    from gmlm_amd import build_rel_csr
+    n, e = 2000, 80000
+    g = torch.Generator().manual_seed(33)
+    w = (torch.arange(n, dtype=torch.float32) + 1).pow(-1.0)
+    ei = torch.stack([torch.multinomial(w, e, True, generator=g), torch.multinomial(w, e, True, generator=g)])
+    csr = build_rel_csr(ei.to(dev), n, 5)
+    for plan, rowptr in ((csr.split, csr.rowptr), (csr.t_split, csr.t_rowptr)):
+        assert plan is not None
+        ls, cp, ow = O.split_plan(rowptr.cpu().numpy(), plan.thresh)
+        assert plan.n_long == ls.size and plan.n_chunks == ow.size
+        assert np.array_equal(plan.long_seg.cpu().numpy(), ls)
+        assert np.array_equal(plan.chunk_ptr.cpu().numpy(), cp)
+        assert np.array_equal(plan.chunk_owner.cpu().numpy(), ow)
