@@ -74,18 +74,23 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
         import math
         # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
         s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
-        while s > 1 and t % s:
-            s //= 2
     if s == 1:
         return dy2.t() @ x2
-    a = dy2.view(s, t // s, n).transpose(1, 2)
-    b = x2.view(s, t // s, k)
+    # a packed batch has an arbitrary token count: S equal slices of floor(T/S) rows + a tail of < S rows
+    q = t // s
+    a = dy2[:s * q].view(s, q, n).transpose(1, 2)
+    b = x2[:s * q].view(s, q, k)
     if _F32_OUT[0] and dy2.dtype != torch.float32:
         try:
-            return torch.bmm(a, b, out_dtype=torch.float32).sum(0).to(dy2.dtype)
+            dw = torch.bmm(a, b, out_dtype=torch.float32).sum(0)
         except (RuntimeError, TypeError):
             _F32_OUT[0] = False
-    return torch.bmm(a, b).float().sum(0).to(dy2.dtype)
+            dw = torch.bmm(a, b).float().sum(0)
+    else:
+        dw = torch.bmm(a, b).float().sum(0)
+    if s * q < t:
+        dw.addmm_(dy2[s * q:].t().float(), x2[s * q:].float())
+    return dw.to(dy2.dtype)
 
 
 class _Linear(torch.autograd.Function):

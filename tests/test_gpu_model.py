@@ -329,3 +329,19 @@ def test_activation_checkpointing_replays_dropout(dev):
     torch.manual_seed(99)
     m.get_graph_embeddings(x, ei).backward(go)
     assert not torch.allclose(m.rgcn1.root.grad, grads[0]["rgcn1.root"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("t", [4096 + 5, 65536 + 37])
+def test_splitk_wgrad_ragged_token_count(dev, t):
+    """Weight gradient of the packed PLM path at a token count no slice count divides (slices + tail)."""
+    from gmlm_amd.bert import _splitk_wgrad
+    g = torch.Generator(device=dev).manual_seed(t)
+    dy = torch.randn(t, 96, device=dev, generator=g) * 0.05
+    x = torch.randn(t, 160, device=dev, generator=g)
+    ref = dy.double().t() @ x.double()
+    out32 = _splitk_wgrad(dy, x)
+    assert out32.dtype == torch.float32 and torch.allclose(out32.double(), ref, rtol=1e-4, atol=1e-3)
+    outb = _splitk_wgrad(dy.bfloat16(), x.bfloat16())
+    refb = dy.bfloat16().double().t() @ x.bfloat16().double()
+    assert outb.dtype == torch.bfloat16
+    assert (outb.double() - refb).abs().max() <= 2 ** -7 * refb.abs().max()

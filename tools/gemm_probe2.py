@@ -1,4 +1,4 @@
-"""Probe: split-K wgrad orientation at the packed token count."""
+"""Probe: split-K wgrad orientation / slice count at the packed token count."""
 import torch, time
 dev = torch.device("cuda")
 def t(fn, n=20):
@@ -10,11 +10,10 @@ T = 90496
 for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072)):
     x = torch.randn(T, K, device=dev, dtype=torch.bfloat16); dy = torch.randn(T, N, device=dev, dtype=torch.bfloat16)
     fl = 2.0 * T * N * K
-    line = f"N={N} K={K}:"
-    for S in (4, 8, 16, 32):
+    p = t(lambda: torch.mm(dy.t(), x)); q = t(lambda: torch.mm(x.t(), dy))
+    print(f"N={N} K={K}: plain mm dyT@x {p:.3f} ({fl/p/1e9:.0f}TF)  xT@dy {q:.3f} ({fl/q/1e9:.0f}TF)", flush=True)
+    for S in (4, 8, 16, 32, 64, 128):
         if T % S: continue
         a = t(lambda: torch.bmm(dy.view(S, T // S, N).transpose(1, 2), x.view(S, T // S, K), out_dtype=torch.float32).sum(0))
         b = t(lambda: torch.bmm(x.view(S, T // S, K).transpose(1, 2), dy.view(S, T // S, N), out_dtype=torch.float32).sum(0))
-        c = t(lambda: torch.bmm(dy.view(S, T // S, N).transpose(1, 2), x.view(S, T // S, K)).float().sum(0))
-        line += f" S={S}: dyT@x {a:.3f} ({fl/a/1e9:.0f}TF) xT@dy {b:.3f} ({fl/b/1e9:.0f}TF) bf16out {c:.3f} |"
-    print(line, flush=True)
+        print(f"   S={S}: dyT@x {a:.3f} ({fl/a/1e9:.0f}TF) xT@dy {b:.3f} ({fl/b/1e9:.0f}TF)", flush=True)
