@@ -123,12 +123,62 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, uint
   const uint32_t w = hash_u32(seed, idx >> 1);
   return ((w >> (16 * (uint32_t)(idx & 1))) & 0xFFFFu) >= thresh16 ? keep_scale : 0.f;
 }
+// keep bits of V consecutive elements starting at `off` (a multiple of V, V even): bit v set = element off+v is
+// kept.  Same decisions as dropout_scale(); the per-chunk part of the hash input is computed once (the low word of
+// (off >> 1) + p cannot carry inside an aligned chunk, so the multiply distributes over the pair index).
+template <int V>
+__device__ __forceinline__ uint32_t dropout_keep_bits(uint64_t seed, uint64_t off, uint32_t thresh16) {
+  const uint64_t i0 = off >> 1;
+  const uint32_t base = (uint32_t)i0 * 0x9E3779B1u + (uint32_t)(i0 >> 32) * 0x85EBCA77u + (uint32_t)seed;
+  const uint32_t hi = (uint32_t)(seed >> 32);
+  uint32_t bits = 0;
+#pragma unroll
+  for (int p = 0; p < V / 2; ++p) {
+    uint32_t x = base + (uint32_t)p * 0x9E3779B1u;
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    x ^= hi;
+    bits |= ((x & 0xFFFFu) >= thresh16 ? 1u : 0u) << (2 * p);
+    bits |= ((x >> 16) >= thresh16 ? 1u : 0u) << (2 * p + 1);
+  }
+  return bits;
+}
 inline uint32_t dropout_threshold(float p) {
   if (p <= 0.f) return 0u;
   long t = lroundf(p * 65536.f);
   return (uint32_t)(t < 0 ? 0 : (t > 65535 ? 65535 : t));
 }
 inline float dropout_keep_scale(uint32_t thresh16) { return 65536.f / (65536.f - (float)thresh16); }
+
+// Branch-free erf for the bf16 kernels (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7, i.e. ~2^-15 of a bf16
+// ulp at 1): ~20 VALU slots against ~40 for the branchy libm erff, which made bias+GELU issue-bound.  Also
+// returns exp(-z^2), which the GELU derivative needs anyway.  The f32 kernels keep erff.
+__device__ __forceinline__ float erf_fast(float z, float& exp_mz2) {
+  const float a = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  p *= t;
+  exp_mz2 = __builtin_amdgcn_exp2f(-1.4426950408889634f * a * a);
+  return copysignf(fmaf(-p, exp_mz2, 1.f), z);
+}
+template <typename T> __device__ __forceinline__ float gelu_fwd_t(float x);
+template <> __device__ __forceinline__ float gelu_fwd_t<float>(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+template <> __device__ __forceinline__ float gelu_fwd_t<bf16_t>(float x) {
+  float e;
+  return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752440f, e));
+}
+template <typename T> __device__ __forceinline__ float gelu_grad_t(float x);
+template <> __device__ __forceinline__ float gelu_grad_t<float>(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752440f));
+  return cdf + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+template <> __device__ __forceinline__ float gelu_grad_t<bf16_t>(float x) {
+  float e;                                                       // = exp(-x^2 / 2)
+  const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752440f, e));
+  return cdf + x * 0.39894228040143267794f * e;
+}
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

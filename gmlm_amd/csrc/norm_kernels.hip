@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void graphnorm_apply_kernel(const TY* __restri
   for (int64_t r = blockIdx.y; r < n; r += gridDim.y) {
     const int64_t i = r * f + c;
     float v = (Store<TY>::ld(x + i) - sub) * a + bb;
-    if (ACT) v = gelu_erf(v);
+    if (ACT) v = gelu_fwd_t<TY>(v);
     if (thresh) v *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
     Store<TY>::st(y + i, v);
   }
@@ -75,7 +75,7 @@ struct GraphNormBwdStatsFn {
     const float oh = (Store<TG>::ld(x + i) - mean[c] * ms[c]) * rstd[c];
     float gz = Store<TG>::ld(g + i);
     if (thresh) gz *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
-    if (ACT) gz *= gelu_erf_grad(w[c] * oh + b[c]);
+    if (ACT) gz *= gelu_grad_t<TG>(w[c] * oh + b[c]);
     v[0] = gz;
     v[1] = gz * oh;
   }
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
     const float oh = (Store<TG>::ld(x + i) - sub) * rs;
     float gz = Store<TG>::ld(g + i);
     if (thresh) gz *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
-    if (ACT) gz *= gelu_erf_grad(wc * oh + bc);
+    if (ACT) gz *= gelu_grad_t<TG>(wc * oh + bc);
     Store<TG>::st(dx + i, wc * rs * (gz - oh * m2) - msc * mean_do);
   }
 }
@@ -176,12 +176,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
         float rr[V];
         if (res) Store<T>::ldv(res + off, rr);
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          z[c][v] += bi[c][v];
-          if (thresh) z[c][v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
-          if (res) z[c][v] += rr[v];
-          sum += z[c][v];
+        for (int v = 0; v < V; ++v) z[c][v] += bi[c][v];
+        if (thresh) {
+          const uint32_t kb = dropout_keep_bits<V>(seed, (uint64_t)off, thresh);
+#pragma unroll
+          for (int v = 0; v < V; ++v) z[c][v] = ((kb >> v) & 1u) ? z[c][v] * keep_scale : 0.f;
         }
+        if (res) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) z[c][v] += rr[v];
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) sum += z[c][v];
       }
     }
     const float mu = group_sum<LPR>(sum) * inv_f;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const float t = (z[c][v] - mu) * rs * gm[c][v] + bt[c][v];
-          o[v] = ACT ? gelu_erf(t) : t;
+          o[v] = ACT ? gelu_fwd_t<T>(t) : t;
         }
         Store<T>::stv(y + r * f + (int64_t)ch * V, o);
       }
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, co
 // backward: each lane keeps partial dgamma/dbeta/dbias for its fixed columns; the 4 waves (x 64/LPR row
 // groups) of a block are summed through LDS in a fixed order and the block writes ONE partial row
 // [3][f]; a second kernel sums the blocks in a fixed tree order (deterministic).
-template <typename T, int CH, int LPR, bool ACT>
+template <typename T, int CH, int LPR, bool ACT, bool DROP, bool RES>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                       const float* __restrict__ bias, const T* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -226,6 +232,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                       int64_t rows, int f, uint32_t thresh, float keep_scale, uint64_t seed,
                                                       T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial) {
   constexpr int V = Store<T>::kVec, RPW = 64 / LPR;
+  static_assert(CH * V <= 32, "keep bits of one row slice must fit one word");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3 * f]
   const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR, wv = threadIdx.x >> 6;
   const int nch = f / V;
@@ -251,6 +258,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     const float mu = live ? mean[r] : 0.f, rs = live ? rstd[r] : 0.f;
     float zh[CH][V], dzh[CH][V];
     float s1 = 0.f, s2 = 0.f;
+    uint32_t keep = 0;                       // dropout decisions of this lane's elements, reused by the dx pass
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int ch = c * LPR + lr;
@@ -259,16 +267,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         float gv[V], rr[V];
         Store<T>::ldv(x + off, zh[c]);
         Store<T>::ldv(dy + off, gv);
-        if (res) Store<T>::ldv(res + off, rr);
+        if (RES) Store<T>::ldv(res + off, rr);
+        uint32_t kb = 0;
+        if (DROP) {
+          kb = dropout_keep_bits<V>(seed, (uint64_t)off, thresh);
+          keep |= kb << (c * V);
+        }
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           float z = zh[c][v] + bi[c][v];
-          if (thresh) z *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
-          if (res) z += rr[v];
+          if (DROP) z = ((kb >> v) & 1u) ? z * keep_scale : 0.f;
+          if (RES) z += rr[v];
           z = (z - mu) * rs;
           zh[c][v] = z;
           float dyn = gv[v];
-          if (ACT) dyn *= gelu_erf_grad(z * gm[c][v] + bt[c][v]);
+          if (ACT) dyn *= gelu_grad_t<T>(z * gm[c][v] + bt[c][v]);
           dg[c][v] += dyn * z;
           db[c][v] += dyn;
           dzh[c][v] = dyn * gm[c][v];
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           dz[v] = rs * (dzh[c][v] - s1 - zh[c][v] * s2);
-          dxv[v] = thresh ? dz[v] * dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale) : dz[v];
+          dxv[v] = DROP ? (((keep >> (c * V + v)) & 1u) ? dz[v] * keep_scale : 0.f) : dz[v];
           dbi[c][v] += dxv[v];
         }
         Store<T>::stv(dx + off, dxv);
@@ -367,7 +380,7 @@ static inline LnGeom ln_geom(int64_t f, int dtype, bool backward = false) {
 
 static inline int ln_bwd_blocks(int64_t rows) {
   int64_t b = cdiv(rows, 8);  // >= 2 rows per wave
-  return (int)(b < 1 ? 1 : (b > 768 ? 768 : b));
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));   // 4 resident blocks per CU (LDS 36 KB each at f = 768)
 }
 
 }  // namespace gmlm
@@ -520,13 +533,16 @@ extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const 
   float* partial = static_cast<float*>(workspace);
   const LnGeom ge = ln_geom(f, dtype, true);
   const size_t lds = (size_t)4 * 3 * f * sizeof(float);
-#define L2(T, C, P, A) ln_bwd_kernel<T, C, P, A><<<blocks, 256, lds, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
+#define L3(T, C, P, A, D, R) ln_bwd_kernel<T, C, P, A, D, R><<<blocks, 256, lds, st>>>((const T*)dy, (const T*)x, bias, (const T*)residual, gamma, beta, mean, rstd, rows, (int)f, th, ks, seed, (T*)dx, (T*)dresidual, partial)
+#define L2(T, C, P, A) do { if (th) { if (residual) L3(T, C, P, A, true, true); else L3(T, C, P, A, true, false); } \
+                            else { if (residual) L3(T, C, P, A, false, true); else L3(T, C, P, A, false, false); } } while (0)
 #define L(T, A) do { if (ge.lpr == 32) { if (ge.ch <= 1) L2(T, 1, 32, A); else if (ge.ch == 2) L2(T, 2, 32, A); else L2(T, 3, 32, A); } \
                      else { if (ge.ch <= 1) L2(T, 1, 64, A); else if (ge.ch == 2) L2(T, 2, 64, A); else if (ge.ch == 3) L2(T, 3, 64, A); else L2(T, 4, 64, A); } } while (0)
   if (dtype == GMLM_F32) { if (act) L(float, true); else L(float, false); }
   else { if (act) L(bf16_t, true); else L(bf16_t, false); }
 #undef L
 #undef L2
+#undef L3
   GMLM_LAUNCH_CHECK();
   ln_bwd_final_kernel<<<(int)cdiv(3 * f, 32), 256, 0, st>>>(partial, blocks, (int)f, dgamma, dbeta, dbias);
   GMLM_LAUNCH_CHECK();

@@ -61,56 +61,80 @@ struct SoftmaskBwdFn {
   __device__ void operator()(int64_t r, int64_t c, float (&v)[1]) const { v[0] = mask[r] ? dout[r * stride + c] : 0.f; }
 };
 
-template <typename T>
+// Threads own V fixed columns (blockDim.x chunk-columns per block, picked on the host so no lane idles) and
+// stream rows blockIdx.y, +gridDim.y, ...; two rows are in flight per iteration.
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                              int64_t rows, int64_t f, uint32_t thresh, float keep_scale,
                                                              uint64_t seed, T* __restrict__ y) {
   constexpr int V = Store<T>::kVec;
   const int64_t nch = f / V;
-  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= nch) return;
   float bv[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) bv[v] = bias ? bias[ch * V + v] : 0.f;
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-    const int64_t off = r * f + ch * V;
-    float a[V];
-    Store<T>::ldv(x + off, a);
+  const int64_t gy = gridDim.y;
+  for (int64_t r = blockIdx.y; r < rows; r += 2 * gy) {
+    const bool two = r + gy < rows;
+    const int64_t off0 = r * f + ch * V, off1 = two ? off0 + gy * f : off0;
+    float a[2][V];
+    Store<T>::ldv(x + off0, a[0]);
+    Store<T>::ldv(x + off1, a[1]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      a[v] = gelu_erf(a[v] + bv[v]);
-      if (thresh) a[v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
+    for (int u = 0; u < 2; ++u) {
+      const int64_t off = u ? off1 : off0;
+      const uint32_t kb = DROP ? dropout_keep_bits<V>(seed, (uint64_t)off, thresh) : 0u;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        a[u][v] = gelu_fwd_t<T>(a[u][v] + bv[v]);
+        if (DROP) a[u][v] = ((kb >> v) & 1u) ? a[u][v] * keep_scale : 0.f;
+      }
     }
-    Store<T>::stv(y + off, a);
+    Store<T>::stv(y + off0, a[0]);
+    if (two) Store<T>::stv(y + off1, a[1]);
   }
 }
 
 // dbias partials ride along: a thread owns V fixed columns, so it keeps their column sums in registers
 // over the rows it streams and writes one partial row per blockIdx.y (summed by rows_sum_kernel).
-template <typename T>
+template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ bias, int64_t rows, int64_t f,
                                                              uint32_t thresh, float keep_scale, uint64_t seed,
                                                              T* __restrict__ dx, float* __restrict__ dbias_partial) {
   constexpr int V = Store<T>::kVec;
   const int64_t nch = f / V;
-  const int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= nch) return;
   float bv[V], acc[V];
 #pragma unroll
   for (int v = 0; v < V; ++v) { bv[v] = bias ? bias[ch * V + v] : 0.f; acc[v] = 0.f; }
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-    const int64_t off = r * f + ch * V;
-    float a[V], g[V];
-    Store<T>::ldv(x + off, a);
-    Store<T>::ldv(dy + off, g);
+  const int64_t gy = gridDim.y;
+  for (int64_t r = blockIdx.y; r < rows; r += 2 * gy) {
+    const bool two = r + gy < rows;
+    const int64_t off0 = r * f + ch * V, off1 = two ? off0 + gy * f : off0;
+    float a[2][V], g[2][V];
+    Store<T>::ldv(x + off0, a[0]);
+    Store<T>::ldv(dy + off0, g[0]);
+    Store<T>::ldv(x + off1, a[1]);
+    Store<T>::ldv(dy + off1, g[1]);
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      if (thresh) g[v] *= dropout_scale(seed, (uint64_t)(off + v), thresh, keep_scale);
-      g[v] *= gelu_erf_grad(a[v] + bv[v]);
-      acc[v] += g[v];
+    for (int u = 0; u < 2; ++u) {
+      const int64_t off = u ? off1 : off0;
+      const uint32_t kb = DROP ? dropout_keep_bits<V>(seed, (uint64_t)off, thresh) : 0u;
+      const bool count = u == 0 || two;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float gv = g[u][v];
+        if (DROP) gv = ((kb >> v) & 1u) ? gv * keep_scale : 0.f;
+        gv *= gelu_grad_t<T>(a[u][v] + bv[v]);
+        g[u][v] = gv;
+        acc[v] += count ? gv : 0.f;
+      }
     }
-    Store<T>::stv(dx + off, g);
+    Store<T>::stv(dx + off0, g[0]);
+    if (two) Store<T>::stv(dx + off1, g[1]);
   }
   if (dbias_partial) {
 #pragma unroll
@@ -131,6 +155,19 @@ static inline dim3 stream_grid(int64_t rows, int64_t cols_units) {
   if (ry > rows) ry = rows;
   if (ry < 1) ry = 1;
   return dim3(ct, (unsigned)ry);
+}
+
+// bias+GELU geometry: chunk-columns per block = the largest of 256/192/128/64 that divides the chunk count (no
+// idle lanes, e.g. 384 chunks -> 2 x 192), row lanes in y so that the grid holds ~`target` blocks.
+struct BgGeom { dim3 grid; unsigned block; };
+static inline BgGeom bg_geom(int64_t rows, int64_t chunks, int64_t target) {
+  unsigned bx = 256;
+  for (unsigned c : {256u, 192u, 128u, 64u}) if (chunks % c == 0) { bx = c; break; }
+  const int ct = (int)cdiv(chunks, bx);
+  int64_t ry = cdiv(target, ct);
+  if (ry > rows) ry = rows;
+  if (ry < 1) ry = 1;
+  return BgGeom{dim3(ct, (unsigned)ry), bx};
 }
 
 }  // namespace gmlm
@@ -210,25 +247,20 @@ extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows
   GMLM_REQUIRE(x && y && aligned16(x) && aligned16(y), "bias_gelu_fwd: null or misaligned pointer");
   const uint32_t th = dropout_threshold(dropout_p);
   const float ks = dropout_keep_scale(th);
-  if (dtype == GMLM_F32)
-    bias_gelu_fwd_kernel<float><<<stream_grid(rows, f / 4), 256, 0, as_stream(stream)>>>((const float*)x, bias, rows, f, th, ks, seed, (float*)y);
-  else
-    bias_gelu_fwd_kernel<bf16_t><<<stream_grid(rows, f / 8), 256, 0, as_stream(stream)>>>((const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)y);
+  const BgGeom ge = bg_geom(rows, f / (dtype == GMLM_F32 ? 4 : 8), 4096);
+#define FW(T, D) bias_gelu_fwd_kernel<T, D><<<ge.grid, ge.block, 0, as_stream(stream)>>>((const T*)x, bias, rows, f, th, ks, seed, (T*)y)
+  if (dtype == GMLM_F32) { if (th) FW(float, true); else FW(float, false); }
+  else { if (th) FW(bf16_t, true); else FW(bf16_t, false); }
+#undef FW
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
 
-static inline dim3 bias_gelu_bwd_grid(int64_t rows, int64_t chunks) {
-  const int ct = (int)cdiv(chunks, 256);
-  int64_t ry = cdiv(1024, ct);
-  if (ry > rows) ry = rows;
-  if (ry < 1) ry = 1;
-  return dim3(ct, (unsigned)ry);
-}
+static inline BgGeom bias_gelu_bwd_geom(int64_t rows, int64_t chunks) { return bg_geom(rows, chunks, 2048); }
 
 extern "C" size_t gmlm_bias_gelu_bwd_workspace_bytes(int64_t rows, int64_t f, int dtype) {
-  const dim3 g = bias_gelu_bwd_grid(rows, f / (dtype == GMLM_F32 ? 4 : 8));
-  return (size_t)g.y * f * sizeof(float);
+  const BgGeom g = bias_gelu_bwd_geom(rows, f / (dtype == GMLM_F32 ? 4 : 8));
+  return (size_t)g.grid.y * f * sizeof(float);
 }
 
 extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
@@ -244,19 +276,19 @@ extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bi
   GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
   const uint32_t th = dropout_threshold(dropout_p);
   const float ks = dropout_keep_scale(th);
-  const dim3 grid = bias_gelu_bwd_grid(rows, f / (dtype == GMLM_F32 ? 4 : 8));
+  const BgGeom ge = bias_gelu_bwd_geom(rows, f / (dtype == GMLM_F32 ? 4 : 8));
   float* partial = nullptr;
   if (dbias) {
     GMLM_REQUIRE(workspace && workspace_bytes >= gmlm_bias_gelu_bwd_workspace_bytes(rows, f, dtype), "bias_gelu_bwd: workspace too small");
     partial = static_cast<float*>(workspace);
   }
-  if (dtype == GMLM_F32)
-    bias_gelu_bwd_kernel<float><<<grid, 256, 0, st>>>((const float*)dy, (const float*)x, bias, rows, f, th, ks, seed, (float*)dx, partial);
-  else
-    bias_gelu_bwd_kernel<bf16_t><<<grid, 256, 0, st>>>((const bf16_t*)dy, (const bf16_t*)x, bias, rows, f, th, ks, seed, (bf16_t*)dx, partial);
+#define BW(T, D) bias_gelu_bwd_kernel<T, D><<<ge.grid, ge.block, 0, st>>>((const T*)dy, (const T*)x, bias, rows, f, th, ks, seed, (T*)dx, partial)
+  if (dtype == GMLM_F32) { if (th) BW(float, true); else BW(float, false); }
+  else { if (th) BW(bf16_t, true); else BW(bf16_t, false); }
+#undef BW
   GMLM_LAUNCH_CHECK();
   if (dbias) {
-    rows_sum_kernel<<<(unsigned)cdiv(f, 32), 256, 0, st>>>(partial, (int)grid.y, f, dbias);
+    rows_sum_kernel<<<(unsigned)cdiv(f, 32), 256, 0, st>>>(partial, (int)ge.grid.y, f, dbias);
     GMLM_LAUNCH_CHECK();
   }
   return GMLM_OK;
