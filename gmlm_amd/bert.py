@@ -39,31 +39,78 @@ def check_supported(plm) -> None:
 
 
 class LayerWeights:
-    """Per-forward view of one BertLayer's parameters in the compute dtype (QKV fused).  Built ONCE per
-    forward and shared by all micro-batches: the casts / concatenation (and, in backward, the gradient casts
-    back to the fp32 masters) then happen once per step instead of once per micro-batch."""
+    """Per-forward view of one BertLayer's parameters: the GEMM operands in the compute dtype (``w*`` / ``bqkv``,
+    no autograd history) next to the fp32 master parameters they were cast from.  Built ONCE per forward and
+    shared by all micro-batches.  The GEMM wrappers below compute with the cached copy and hand the weight /
+    bias gradients straight to the MASTERS in fp32 (the split-K partial sums are fp32 already), so neither the
+    per-weight cast kernels nor their backward casts exist."""
+    __slots__ = ("wqkv", "bqkv", "wo", "wi", "wo2", "m_qkv", "m_wo", "m_wi", "m_wo2", "bo", "bi", "bo2", "ln1w", "ln1b",
+                 "ln2w", "ln2b")
 
-    def __init__(self, layer, cd):
-        sa, so = layer.attention.self, layer.attention.output
-        c = lambda t: t.to(cd)
-        self.wqkv = c(torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0))
-        self.bqkv = c(torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0))
-        self.wo, self.bo = c(so.dense.weight), so.dense.bias
-        self.ln1w, self.ln1b = so.LayerNorm.weight, so.LayerNorm.bias
-        self.wi, self.bi = c(layer.intermediate.dense.weight), layer.intermediate.dense.bias
-        self.wo2, self.bo2 = c(layer.output.dense.weight), layer.output.dense.bias
-        self.ln2w, self.ln2b = layer.output.LayerNorm.weight, layer.output.LayerNorm.bias
+
+def _layer_masters(layer):
+    sa, so = layer.attention.self, layer.attention.output
+    return ([sa.query.weight, sa.key.weight, sa.value.weight], [sa.query.bias, sa.key.bias, sa.value.bias],
+            so.dense.weight, layer.intermediate.dense.weight, layer.output.dense.weight)
 
 
 def prepare_weights(plm, cd):
-    return [LayerWeights(layer, cd) for layer in plm.encoder.layer]
+    """One flat buffer in the compute dtype for all layers' GEMM weights, filled by ONE multi-tensor copy
+    (Q/K/V rows land directly in the fused [3P, P] operand, so there is no concatenation either)."""
+    layers = list(plm.encoder.layer)
+    out, srcs, dsts = [], [], []
+    with torch.no_grad():
+        dev = layers[0].attention.self.query.weight.device if layers else None
+
+        def take(shape):
+            nonlocal off
+            n = 1
+            for d in shape:
+                n *= d
+            v = flat[off:off + n].view(shape)
+            off += padded(n)
+            return v
+
+        def padded(n):                                        # keep every operand 256-byte aligned
+            return (n + 127) // 128 * 128
+
+        total = 0
+        for layer in layers:
+            wq, bq, wo, wi, wo2 = _layer_masters(layer)
+            total += padded(sum(t.numel() for t in wq)) + padded(sum(t.numel() for t in bq)) + padded(wo.numel()) \
+                + padded(wi.numel()) + padded(wo2.numel())
+        flat = torch.empty(total, dtype=cd, device=dev)
+        off = 0
+        for layer in layers:
+            sa, so = layer.attention.self, layer.attention.output
+            wq, bq, wo, wi, wo2 = _layer_masters(layer)
+            lw = LayerWeights()
+            p = wq[0].shape[1]
+            lw.wqkv = take((sum(t.shape[0] for t in wq), p))
+            lw.bqkv = take((sum(t.shape[0] for t in bq),))
+            lw.wo, lw.wi, lw.wo2 = take(tuple(wo.shape)), take(tuple(wi.shape)), take(tuple(wo2.shape))
+            r = 0
+            for w_, b_ in zip(wq, bq):
+                dsts += [lw.wqkv[r:r + w_.shape[0]], lw.bqkv[r:r + w_.shape[0]]]
+                srcs += [w_.detach(), b_.detach()]
+                r += w_.shape[0]
+            dsts += [lw.wo, lw.wi, lw.wo2]
+            srcs += [wo.detach(), wi.detach(), wo2.detach()]
+            lw.m_qkv, lw.m_wo, lw.m_wi, lw.m_wo2 = tuple(wq) + tuple(bq), (wo,), (wi,), (wo2,)
+            lw.bo, lw.bi, lw.bo2 = so.dense.bias, layer.intermediate.dense.bias, layer.output.dense.bias
+            lw.ln1w, lw.ln1b = so.LayerNorm.weight, so.LayerNorm.bias
+            lw.ln2w, lw.ln2b = layer.output.LayerNorm.weight, layer.output.LayerNorm.bias
+            out.append(lw)
+        if dsts:
+            torch._foreach_copy_(dsts, srcs)
+    return out
 
 
 _F32_OUT = [True]          # torch.bmm(..., out_dtype=float32) available (checked on first use)
 
 
-def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
-    """dW [N, K] = dy2^T [N, T] @ x2 [T, K].  The reduction dim is the token count (10^4..10^5) while the
+def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor, keep_fp32: bool = False) -> torch.Tensor:
+    """dW [N, K] = dy2^T [N, T] @ x2 [T, K] (returned in fp32 when ``keep_fp32``, else in dy2's dtype).  The reduction dim is the token count (10^4..10^5) while the
     output is only a few 256x256 tiles, so one hipBLASLt call leaves most CUs idle; cutting T into S
     slices (batched GEMM, fp32 partials) and adding them fills the chip (measured 1.5-2.7x on MI355X)."""
     t, n = dy2.shape
@@ -75,7 +122,8 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
         # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
         s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
     if s == 1:
-        return dy2.t() @ x2
+        dw = dy2.t() @ x2
+        return dw.float() if keep_fp32 else dw
     # a packed batch has an arbitrary token count: S equal slices of floor(T/S) rows + a tail of < S rows
     q = t // s
     a = dy2[:s * q].view(s, q, n).transpose(1, 2)
@@ -89,48 +137,70 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor) -> torch.Tensor:
     else:
         dw = torch.bmm(a, b).float().sum(0)
     if s * q < t:
-        dw.addmm_(dy2[s * q:].t().float(), x2[s * q:].float())
-    return dw.to(dy2.dtype)
+        dw += dy2[s * q:].t() @ x2[s * q:]         # < S rows: one tiny GEMM, added in fp32
+    return dw if keep_fp32 else dw.to(dy2.dtype)
 
 
 class _Linear(torch.autograd.Function):
-    """y = x @ w^T (+ b) on hipBLASLt; backward uses the split-K weight gradient above."""
+    """y = x @ wc^T (+ bc) on hipBLASLt with the cached compute-dtype operands ``wc`` / ``bc``; the gradients go
+    to the fp32 MASTER parameters (``masters`` = the weight(s) whose rows stack up to ``wc``, then the bias(es)
+    stacking up to ``bc``): split-K weight gradient and the bias column sum stay in fp32 end to end.
+    With ``residual`` the input is also returned as a second output for the residual branch, so that the two
+    gradients of ``x`` meet HERE and the data-gradient GEMM accumulates onto the residual one (beta = 1 in the
+    GEMM epilogue) instead of autograd running a separate add kernel."""
 
     @staticmethod
-    def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        ctx.has_bias = b is not None
-        return torch.nn.functional.linear(x, w, b)
+    def forward(ctx, x, wc, bc, residual, *masters):
+        ctx.save_for_backward(x, wc)
+        ctx.masters = masters
+        ctx.n_w = len(masters) if bc is None else len(masters) // 2
+        ctx.has_bias = bc is not None
+        y = torch.nn.functional.linear(x, wc, bc)
+        return (y, x.view_as(x)) if residual else y
 
     @staticmethod
-    def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+    def backward(ctx, dy, dxres=None):
+        x, wc = ctx.saved_tensors
+        masters, n_w = ctx.masters, ctx.n_w
         dy2 = dy.reshape(-1, dy.shape[-1])
         x2 = x.reshape(-1, x.shape[-1])
-        dx = (dy2 @ w).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = _splitk_wgrad(dy2, x2) if ctx.needs_input_grad[1] else None
-        db = dy2.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (dy2 @ wc if dxres is None else torch.addmm(dxres.reshape(-1, x.shape[-1]), dy2, wc)).view(x.shape)
+        grads = [None] * len(masters)
+        need = ctx.needs_input_grad[4:]
+        if any(need[:n_w]):
+            dw = _splitk_wgrad(dy2, x2, keep_fp32=True)
+            for i, (m, g) in enumerate(zip(masters[:n_w], dw.split([m.shape[0] for m in masters[:n_w]], 0))):
+                if need[i]:
+                    grads[i] = g if g.dtype == m.dtype else g.to(m.dtype)
+        if ctx.has_bias and any(need[n_w:]):
+            db = dy2.sum(0, dtype=torch.float32)
+            for i, (m, g) in enumerate(zip(masters[n_w:], db.split([m.shape[0] for m in masters[n_w:]], 0))):
+                if need[n_w + i]:
+                    grads[n_w + i] = g if g.dtype == m.dtype else g.to(m.dtype)
+        return (dx, None, None, None, *grads)
 
 
-def _mm(x, w, b=None):
+def _mm(x, wc, bc, masters, residual=False):
     with torch.autocast("cuda", enabled=False):
-        return _Linear.apply(x, w, b)
+        return _Linear.apply(x, wc, bc, residual, *masters)
 
 
 def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None):
     pdim = h.shape[-1]
     d = pdim // heads
-    qkv = _mm(h, lw.wqkv, lw.bqkv)                                                  # [B, L, 3P] or packed [T, 3P]
+    qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv, residual=True)                 # [B, L, 3P] or packed [T, 3P]
     scale = d ** -0.5
     if d in (64, 96):
         ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len, pair_count)
     else:
         ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
                                 training)
-    a = ops.bias_res_layernorm(_mm(ctx, lw.wo), lw.bo, h, lw.ln1w, lw.ln1b, eps, False, p_hidden, training)
-    m = ops.bias_gelu(_mm(a, lw.wi), lw.bi)
-    return ops.bias_res_layernorm(_mm(m, lw.wo2), lw.bo2, a, lw.ln2w, lw.ln2b, eps, False, p_hidden, training)
+    a = ops.bias_res_layernorm(_mm(ctx, lw.wo, None, lw.m_wo), lw.bo, h_res, lw.ln1w, lw.ln1b, eps, False, p_hidden, training)
+    m_pre, a_res = _mm(a, lw.wi, None, lw.m_wi, residual=True)
+    m = ops.bias_gelu(m_pre, lw.bi)
+    return ops.bias_res_layernorm(_mm(m, lw.wo2, None, lw.m_wo2), lw.bo2, a_res, lw.ln2w, lw.ln2b, eps, False, p_hidden, training)
 
 
 def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtype, training: bool = False,
