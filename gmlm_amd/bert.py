@@ -166,7 +166,12 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = (dy2 @ wc if dxres is None else torch.addmm(dxres.reshape(-1, x.shape[-1]), dy2, wc)).view(x.shape)
+            if dxres is None:
+                dx = (dy2 @ wc).view(x.shape)
+            else:
+                # the residual gradient buffer is ours alone (it was produced for this node): accumulate in place
+                dres2 = dxres.reshape(-1, x.shape[-1])
+                dx = (dres2.addmm_(dy2, wc) if dres2.is_contiguous() else torch.addmm(dres2, dy2, wc)).view(x.shape)
         grads = [None] * len(masters)
         need = ctx.needs_input_grad[4:]
         if any(need[:n_w]):

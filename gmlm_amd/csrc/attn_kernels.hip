@@ -263,6 +263,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   if ((int64_t)blockIdx.x * (NW * 32) >= (false ? lk_ : lq_)) return;   // varlen: tile past this sequence (block-uniform)
   const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool q_ok = q_row < lq_;
+  // a wave whose 32 queries all lie past the sequence (short packed sequences) only helps staging K/V
+  const bool wave_live = (int64_t)blockIdx.x * (NW * 32) + w * 32 < lq_;
   int64_t kvlen = lk_;
   if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
   const T* qg = static_cast<const T*>(p.q) + (qbase + (q_ok ? q_row : 0)) * p.q_stride + hd * D;
@@ -298,6 +300,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
       kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
       vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
     }
+    if (wave_live) {
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) mma_acc<D>(vs[cur], PITCH, kb * 32, s[kb], o, lane);
+    }
     if (DBUF) {
       if (more) {
         kr.store(ks[cur ^ 1], tid);
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   if ((int64_t)blockIdx.x * (NW * 32) >= (false ? lk_ : lq_)) return;   // varlen: tile past this sequence (block-uniform)
   const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool q_ok = q_row < lq_;
+  const bool wave_live = (int64_t)blockIdx.x * (NW * 32) + w * 32 < lq_;   // else: staging helper only
   int64_t kvlen = lk_;
   if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
   const int64_t qr = q_ok ? q_row : 0;
@@ -465,6 +470,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
       kr.load(kg, p.k_stride, kv0 + KT, lk_, tid);
       vr.load(vg, p.v_stride, kv0 + KT, lk_, tid);
     }
+    if (wave_live) {
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       f32x16 s, dp;
@@ -480,6 +486,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
         s[i] = pr * (dp[i] * ms - dl);
       }
       mma_acc<D>(ks[cur], PITCH, kb * 32, s, dq, lane);
+    }
     }
     if (DBUF) {
       if (more) {
@@ -526,6 +533,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   const int64_t key = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
   const bool key_in = key < lk_;           // row exists in memory
   const bool key_ok = key < kvlen;          // takes part in the softmax
+  const bool wave_live = (int64_t)blockIdx.x * (NW * 32) + w * 32 < kvlen;   // else: staging helper only (dK = dV = 0)
   const int64_t kr_ = key_in ? key : 0;
   RowFrag<T, D> kf, vf;
   kf.load(static_cast<const T*>(p.k) + (kbase + kr_) * p.k_stride + hd * D, key_in, h);
@@ -577,6 +585,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         dor.load(dog, p.h * D, q0 + QT, lq_, tid);
         load_small(q0 + QT);
       }
+      if (wave_live) {
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
@@ -592,6 +601,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
       }
       mma_acc<D>(dos[cur], PITCH, 0, s, dv, lane);
       mma_acc<D>(qs[cur], PITCH, 0, dp, dk, lane);
+      }
       if (DBUF) {
         if (more) {
           qr.store(qs[cur ^ 1], tid);

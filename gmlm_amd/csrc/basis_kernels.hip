@@ -12,6 +12,11 @@ namespace gmlm {
 
 constexpr int kMaxRB = 5 * 32;   // R_a * B coefficients kept in LDS
 
+// The basis rows of one column chunk lie in*out*4 bytes apart, so a serial loop over b is a chain of dependent
+// long-latency loads.  Both kernels therefore fetch the rows in groups of kGroup with unconditional loads (the
+// row index is clamped, the use is predicated) so that kGroup 16-byte loads are in flight per thread.
+constexpr int kGroup = 6;
+
 __global__ __launch_bounds__(256) void basis_compose_fwd_kernel(const float* __restrict__ comp, const float* __restrict__ weight,
                                                                  int ra, int nb, int64_t cols, float* __restrict__ w) {
   __shared__ float cs[kMaxRB];
@@ -22,14 +27,23 @@ __global__ __launch_bounds__(256) void basis_compose_fwd_kernel(const float* __r
     float4 acc[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < nb; ++b) {
-      const float4 x = *reinterpret_cast<const float4*>(weight + (int64_t)b * cols + ch * 4);
+    for (int b0 = 0; b0 < nb; b0 += kGroup) {
+      float4 x[kGroup];
 #pragma unroll
-      for (int r = 0; r < 5; ++r)
-        if (r < ra) {
-          const float c = cs[r * nb + b];
-          acc[r].x = fmaf(c, x.x, acc[r].x); acc[r].y = fmaf(c, x.y, acc[r].y);
-          acc[r].z = fmaf(c, x.z, acc[r].z); acc[r].w = fmaf(c, x.w, acc[r].w);
+      for (int j = 0; j < kGroup; ++j) {
+        const int b = b0 + j < nb ? b0 + j : nb - 1;
+        x[j] = *reinterpret_cast<const float4*>(weight + (int64_t)b * cols + ch * 4);
+      }
+#pragma unroll
+      for (int j = 0; j < kGroup; ++j)
+        if (b0 + j < nb) {
+#pragma unroll
+          for (int r = 0; r < 5; ++r)
+            if (r < ra) {
+              const float c = cs[r * nb + b0 + j];
+              acc[r].x = fmaf(c, x[j].x, acc[r].x); acc[r].y = fmaf(c, x[j].y, acc[r].y);
+              acc[r].z = fmaf(c, x[j].z, acc[r].z); acc[r].w = fmaf(c, x[j].w, acc[r].w);
+            }
         }
     }
 #pragma unroll
@@ -49,28 +63,40 @@ __global__ __launch_bounds__(256) void basis_compose_bwd_kernel(const float* __r
   __syncthreads();
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t nch = cols / 4;
-  float dc[RA][32];
+  float dc[RA][36];                         // 32 rounded up to a multiple of kGroup; entries >= nb stay 0
 #pragma unroll
   for (int r = 0; r < RA; ++r)
 #pragma unroll
-    for (int b = 0; b < 32; ++b) dc[r][b] = 0.f;
+    for (int b = 0; b < 36; ++b) dc[r][b] = 0.f;
   for (int64_t ch = (int64_t)blockIdx.x * 256 + threadIdx.x; ch < nch; ch += (int64_t)gridDim.x * 256) {
     float4 g[RA];
 #pragma unroll
     for (int r = 0; r < RA; ++r) g[r] = *reinterpret_cast<const float4*>(dw + (int64_t)r * cols + ch * 4);
 #pragma unroll
-    for (int b = 0; b < 32; ++b)
-      if (b < nb) {
-        const float4 x = *reinterpret_cast<const float4*>(weight + (int64_t)b * cols + ch * 4);
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b0 = 0; b0 < 36; b0 += kGroup) {
+      if (b0 < nb) {                        // block-uniform
+        float4 x[kGroup];
 #pragma unroll
-        for (int r = 0; r < RA; ++r) {
-          const float c = cs[r * nb + b];
-          o.x = fmaf(c, g[r].x, o.x); o.y = fmaf(c, g[r].y, o.y); o.z = fmaf(c, g[r].z, o.z); o.w = fmaf(c, g[r].w, o.w);
-          dc[r][b] += g[r].x * x.x + g[r].y * x.y + g[r].z * x.z + g[r].w * x.w;
+        for (int j = 0; j < kGroup; ++j) {
+          const int b = b0 + j < nb ? b0 + j : nb - 1;
+          x[j] = *reinterpret_cast<const float4*>(weight + (int64_t)b * cols + ch * 4);
         }
-        *reinterpret_cast<float4*>(dweight + (int64_t)b * cols + ch * 4) = o;
+#pragma unroll
+        for (int j = 0; j < kGroup; ++j) {
+          const int b = b0 + j;
+          if (b < nb) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int r = 0; r < RA; ++r) {
+              const float c = cs[r * nb + b];
+              o.x = fmaf(c, g[r].x, o.x); o.y = fmaf(c, g[r].y, o.y); o.z = fmaf(c, g[r].z, o.z); o.w = fmaf(c, g[r].w, o.w);
+              dc[r][b] += g[r].x * x[j].x + g[r].y * x[j].y + g[r].z * x[j].z + g[r].w * x[j].w;
+            }
+            *reinterpret_cast<float4*>(dweight + (int64_t)b * cols + ch * 4) = o;
+          }
+        }
       }
+    }
   }
   // block reduction of dcomp in a fixed order: wave shuffle tree, then the 4 waves through LDS
 #pragma unroll
