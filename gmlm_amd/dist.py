@@ -247,10 +247,81 @@ class PartitionContext:
         flush()
 
 
-def attach_partition(model, edge_index: torch.Tensor, n_total: int, device, group=None, edge_type=None) -> PartitionContext:
-    """Partition the (replicated, static) graph for this rank and attach the context to ``model``."""
+# ---------------------------------------------------------------------------------------------
+# partition shard files: one pickle-free .npz per rank, so a graph is partitioned once (offline, on the host)
+# and a rank of a later run reads only its own shard instead of the whole edge list
+# ---------------------------------------------------------------------------------------------
+PARTITION_FORMAT = "gmlm-partition-v1"
+_PLAN_ARRAYS = ("local_edge_index", "local_edge_type", "halo_ids", "send_idx")
+
+
+def partition_file(directory: str, rank: int, world: int) -> str:
+    import os
+    return os.path.join(directory, f"part-{rank:05d}-of-{world:05d}.npz")
+
+
+def save_partition(plan: PartitionPlan, path: str) -> None:
+    """Write one rank's plan: int64 index arrays + a small int64 header (numpy ``savez``, no pickled objects)."""
+    import numpy as np
+    arrays = {k: getattr(plan, k).cpu().numpy().astype(np.int64) for k in _PLAN_ARRAYS}
+    arrays["header"] = np.asarray([plan.n_total, plan.world, plan.rank, plan.lo, plan.hi], dtype=np.int64)
+    arrays["recv_counts"] = np.asarray(plan.recv_counts, dtype=np.int64)
+    arrays["send_counts"] = np.asarray(plan.send_counts, dtype=np.int64)
+    arrays["active_relations"] = np.asarray(plan.active_relations, dtype=np.int64)
+    arrays["format"] = np.frombuffer(PARTITION_FORMAT.encode(), dtype=np.uint8)
+    np.savez(path, **arrays)
+
+
+def load_partition(path: str, world: Optional[int] = None, rank: Optional[int] = None) -> PartitionPlan:
+    """Read a shard written by ``save_partition``; checks the format tag, the (world, rank) it was made for
+    and the internal consistency of the counts before anything is launched with it."""
+    import numpy as np
+    with np.load(path, allow_pickle=False) as z:
+        if "format" not in z.files or bytes(z["format"]).decode() != PARTITION_FORMAT:
+            raise ValueError(f"{path}: not a {PARTITION_FORMAT} file")
+        n_total, w, r, lo, hi = (int(v) for v in z["header"])
+        t = {k: torch.from_numpy(z[k].astype(np.int64)) for k in _PLAN_ARRAYS}
+        recv, send = [int(v) for v in z["recv_counts"]], [int(v) for v in z["send_counts"]]
+        active = [int(v) for v in z["active_relations"]]
+    if world is not None and (w != world or (rank is not None and r != rank)):
+        raise ValueError(f"{path}: shard is rank {r} of {w}, wanted rank {rank} of {world}")
+    if (lo, hi) != row_range(n_total, w, r) or len(recv) != w or len(send) != w:
+        raise ValueError(f"{path}: header does not describe a 1-D row partition")
+    if sum(recv) != t["halo_ids"].numel() or sum(send) != t["send_idx"].numel() or recv[r] or send[r]:
+        raise ValueError(f"{path}: exchange counts do not match the index arrays")
+    ei = t["local_edge_index"]
+    n_loc, n_src = hi - lo, hi - lo + t["halo_ids"].numel()
+    if ei.numel() and (int(ei[1].max()) >= n_loc or int(ei[0].max()) >= n_src or int(ei.min()) < 0):
+        raise ValueError(f"{path}: local edge index out of range")
+    if t["send_idx"].numel() and (int(t["send_idx"].max()) >= n_loc or int(t["send_idx"].min()) < 0):
+        raise ValueError(f"{path}: send index out of range")
+    return PartitionPlan(n_total, w, r, lo, hi, ei, t["local_edge_type"], t["halo_ids"], recv, t["send_idx"], send, active)
+
+
+def write_partition_files(edge_index: torch.Tensor, n_total: int, world: int, directory: str,
+                          edge_type: Optional[torch.Tensor] = None) -> List[str]:
+    """Offline step: partition a graph for ``world`` ranks and write one shard per rank."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    paths = []
+    for r in range(world):
+        path = partition_file(directory, r, world)
+        save_partition(plan_partition(edge_index, n_total, world, r, edge_type), path)
+        paths.append(path)
+    return paths
+
+
+def attach_partition(model, edge_index: Optional[torch.Tensor], n_total: int, device, group=None, edge_type=None,
+                     partition_dir: Optional[str] = None) -> PartitionContext:
+    """Partition the (replicated, static) graph for this rank — or read this rank's shard from
+    ``partition_dir`` — and attach the context to ``model``."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    plan = plan_partition(edge_index, n_total, world, rank, edge_type)
+    if partition_dir is not None:
+        plan = load_partition(partition_file(partition_dir, rank, world), world, rank)
+        if plan.n_total != n_total:
+            raise ValueError(f"partition shard is for {plan.n_total} nodes, the graph has {n_total}")
+    else:
+        plan = plan_partition(edge_index, n_total, world, rank, edge_type)
     ctx = PartitionContext(plan, device, group)
     ctx.build_csr(model.num_relations)
     model.dist = ctx
