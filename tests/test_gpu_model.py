@@ -345,3 +345,52 @@ def test_splitk_wgrad_ragged_token_count(dev, t):
     refb = dy.bfloat16().double().t() @ x.bfloat16().double()
     assert outb.dtype == torch.bfloat16
     assert (outb.double() - refb).abs().max() <= 2 ** -7 * refb.abs().max()
+
+
+@pytest.mark.parametrize("case", ["no_edges", "self_loops_and_duplicates", "one_active_one_token", "hub"])
+def test_edge_case_graphs_vs_oracle(dev, case):
+    """Degenerate inputs the reference accepts, logits within 1e-4 of the oracle in fp32: a graph without edges
+    (every aggregation segment empty), only self loops + repeated edges (collisions inside a segment), a single
+    active node whose text is one token (shortest packed sequence), one hub that every edge points to and from."""
+    import gmlm_amd
+    plm = dict(hidden=128, layers=2, heads=2, inter=256, max_pos=64, vocab=200)
+    n = 40
+    cfg = dict(n=n, e=0, f_in=24, hc=16, c=3, plm=plm, seed=77, max_len=16)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 24, generator=g)
+    y = torch.randint(0, 3, (n,), generator=g)
+    mask = torch.rand(n, generator=g) < 0.5
+    ids, am = O.synthetic_tokens(n, 16, 200, 5, 2)
+    if case == "no_edges":
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    elif case == "self_loops_and_duplicates":
+        a = torch.arange(n)
+        ei = torch.cat([torch.stack([a, a]), torch.tensor([[3, 3, 3, 3, 7, 7], [5, 5, 5, 5, 5, 5]])], 1)
+    elif case == "hub":
+        a = torch.arange(1, n)
+        ei = torch.cat([torch.stack([a, torch.zeros_like(a)]), torch.stack([torch.zeros_like(a), a])], 1)
+    else:
+        ei = torch.randint(0, n, (2, 90), generator=g)
+        mask = torch.zeros(n, dtype=torch.bool)
+        mask[11] = True
+        am[11] = 0
+        am[11, 0] = 1
+    om, _ = oracle_model_from_config(cfg)
+    xm_ref = O.soft_masking_gnn_input(x, mask, om.gnn_mask_token_embed, 0.7)
+    ref = om(xm_ref, ei, ids, am, mask, plm_batch_size=8)
+    loss_ref = F.cross_entropy(ref[mask], y[mask], label_smoothing=0.2)
+    loss_ref.backward()
+    m = build_model(cfg, dev, compute_dtype=torch.float32).train()
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    xm = m.soft_mask_input(x.to(dev), mask.to(dev), 0.7)
+    logits = m(xm, ei.to(dev), tokens, mask.to(dev), plm_batch_size=8)
+    loss = F.cross_entropy(logits[mask.to(dev)], y.to(dev)[mask.to(dev)], label_smoothing=0.2)
+    loss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), ref.detach().numpy(), rtol=0, atol=1e-4)
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
+    for k in ("rgcn1.weight", "rgcn4.root", "gnorm2.weight", "gnn_mask_token_embed", "classifier.3.weight"):
+        r, p = dict(om.named_parameters())[k].grad, dict(m.named_parameters())[k].grad
+        if r is None:
+            assert p is None or float(p.abs().max()) == 0
+            continue
+        np.testing.assert_allclose(p.cpu().numpy(), r.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
