@@ -403,7 +403,7 @@ def main():
             ach = s["bytes"] / s["ms"] / 1e6
             out["roofline"] = {"kernel": "seg_reduce_vec_kernel (RGCN mean aggregation, forward, 4 layers/step)",
                                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("spmm_fwd_in_step"),
+                               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("spmm_fwd_in_step") if world == 1 else None,
                                "algorithmic_bytes_per_launch": round(s["bytes"] / s["launches"]),
                                "avg_launch_ms": round(s["ms"] / s["launches"], 4)}
         out["kernels"] = kern
