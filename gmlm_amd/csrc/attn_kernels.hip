@@ -515,10 +515,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
 //   S = Q K^T, P = exp(scale*S - lse[q]), dV^T += dO^T P, dP = dO V^T, dS = P*(dP - delta[q]),
 //   dK^T += Q^T dS   (all with the key on the lane, the query in the accumulator registers)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int NW, bool DROP>
+// QT = query rows staged per barrier: 32 with two LDS buffers (long sequences: loads of tile t+1 under the MFMAs
+// of tile t), or 128 in one buffer for sequences of <= 128 tokens (the whole sequence behind ONE barrier: at
+// 16-128 tokens the per-tile barrier / LDS round trip, not the MFMA work, sets the block's lifetime).
+template <typename T, int D, int NW, bool DROP, int QT = 32>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr bool DBUF = sizeof(T) == 2;
-  constexpr int QT = 32, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
+  constexpr bool DBUF = sizeof(T) == 2 && QT == 32;
+  constexpr int NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
   __shared__ __attribute__((aligned(16))) T qs[NBUF][QT * PITCH];
   __shared__ __attribute__((aligned(16))) T dos[NBUF][QT * PITCH];
   __shared__ float lse_s[NBUF][QT];
@@ -586,21 +589,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         load_small(q0 + QT);
       }
       if (wave_live) {
-      f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-      mma_rows<D>(qs[cur], PITCH, 0, kf, s, r, h);
-      mma_rows<D>(dos[cur], PITCH, 0, vf, dp, r, h);
+      for (int qb = 0; qb < QT / 32; ++qb) {
+        if (QT > 32 && q0 + qb * 32 >= lq_) break;            // block-uniform
+        f32x16 s, dp;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int qi = acc_row(i, h);
-        const float pr = (key_ok && q0 + qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
-        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
-        s[i] = pr * ms;
-        dp[i] = pr * (dp[i] * ms - dl_s[cur][qi]);
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        mma_rows<D>(qs[cur], PITCH, qb * 32, kf, s, r, h);
+        mma_rows<D>(dos[cur], PITCH, qb * 32, vf, dp, r, h);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int qi = qb * 32 + acc_row(i, h);
+          const float pr = (key_ok && q0 + qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
+          const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+          s[i] = pr * ms;
+          dp[i] = pr * (dp[i] * ms - dl_s[cur][qi]);
+        }
+        mma_acc<D>(dos[cur], PITCH, qb * 32, s, dv, lane);
+        mma_acc<D>(qs[cur], PITCH, qb * 32, dp, dk, lane);
       }
-      mma_acc<D>(dos[cur], PITCH, 0, s, dv, lane);
-      mma_acc<D>(qs[cur], PITCH, 0, dp, dk, lane);
       }
       if (DBUF) {
         if (more) {
@@ -619,6 +626,161 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         store_small(0);
         __syncthreads();
       }
+    }
+  }
+  if (key_in) {
+    T* dkg = static_cast<T*>(p.dk) + (kbase + key) * p.dk_stride + hd * D;
+    T* dvg = static_cast<T*>(p.dv) + (kbase + key) * p.dv_stride + hd * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+      store_t<T>(dkg + d * 32, dk[d], p.scale, h);
+      store_t<T>(dvg + d * 32, dv[d], 1.f, h);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, sequences of <= 128 tokens (bf16): ONE launch per (sequence, head).  Q, K, V and dO of the sequence
+// are staged in LDS once (8 tensor passes over HBM instead of the 13 of delta + dQ + dK/dV kernels, which at
+// 16-128 tokens are bound by exactly that traffic and by per-launch latency, not by the MFMAs).  Phase 1 is the
+// dQ kernel's body (query on the lane, delta = rowsum(dO*O) computed in place), phase 2 the dK/dV kernel's body
+// (key on the lane); both read only LDS.  The reference tokenises to max_length = 128 (main.py:340).
+// ------------------------------------------------------------------------------------------------
+template <int D, bool DROP>
+__global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
+  using T = bf16_t;
+  constexpr int R = 128, NT = 256, PITCH = D + Pad<T>::v, DB = D / 32, CPR = D / 8, PER = R * CPR / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* ta = reinterpret_cast<T*>(smem_raw);          // K, then Q
+  T* tb = ta + R * PITCH;                          // V, then dO
+  float* lse_s = reinterpret_cast<float*>(tb + R * PITCH);
+  float* dl_s = lse_s + R;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.x / p.h, hd = blockIdx.x % p.h;
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  int64_t kvlen = lk_;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
+  const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
+  const T* dog = static_cast<const T*>(p.dout) + (qbase * p.h + hd) * D;
+  const T* og = static_cast<const T*>(p.out) + (qbase * p.h + hd) * D;
+  const int64_t do_stride = p.h * D;
+  // two tiles at a time through the same LDS image; only the 32-row blocks the sequence touches are written
+  auto stage2 = [&](const T* ga, int64_t sa, const T* gb, int64_t sb, int64_t len) {
+    const int need = (int)((len + 31) / 32) * 32;
+    uint4 a[PER], c[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
+      a[k] = make_uint4(0, 0, 0, 0);
+      c[k] = make_uint4(0, 0, 0, 0);
+      if (row < len) {
+        a[k] = *reinterpret_cast<const uint4*>(ga + row * sa + col);
+        c[k] = *reinterpret_cast<const uint4*>(gb + row * sb + col);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
+      if (row < need) {
+        *reinterpret_cast<uint4*>(ta + row * PITCH + col) = a[k];
+        *reinterpret_cast<uint4*>(tb + row * PITCH + col) = c[k];
+      }
+    }
+  };
+  stage2(kg, p.k_stride, vg, p.v_stride, lk_);
+  const float sl2 = p.scale * kLog2e;
+  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
+  // ---- phase 1: dQ (query on the lane; K, V in LDS) ---------------------------------------------------
+  const int64_t q_row = w * 32 + r;
+  const bool q_ok = q_row < lq_;
+  const bool q_wave = w * 32 < lq_;
+  RowFrag<T, D> qf, dof;
+  float lse2 = 0.f, dl = 0.f;
+  if (q_wave) {
+    const int64_t qr = q_ok ? q_row : 0;
+    qf.load(qg + qr * p.q_stride, q_ok, h);
+    dof.load(dog + qr * do_stride, q_ok, h);
+    RowFrag<T, D> of;
+    of.load(og + qr * do_stride, q_ok, h);
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dl = fmaf((float)dof.v[s][j], (float)of.v[s][j], dl);
+    dl = xhalf_sum(dl);
+    lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : 0.f;
+    if (h == 0) { lse_s[q_row] = lse2; dl_s[q_row] = dl; }
+  }
+  __syncthreads();
+  if (q_wave) {
+    const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
+    f32x16 dq[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < R / 32; ++kb) {
+      if (kb * 32 >= kvlen) break;                        // block-uniform
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      mma_rows<D>(ta, PITCH, kb * 32, qf, s, r, h);
+      mma_rows<D>(tb, PITCH, kb * 32, dof, dp, r, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t key = kb * 32 + acc_row(i, h);
+        const float pr = (key < kvlen && q_ok) ? fast_exp2(fmaf(s[i], sl2, -lse2)) : 0.f;
+        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        s[i] = pr * (dp[i] * ms - dl);
+      }
+      mma_acc<D>(ta, PITCH, kb * 32, s, dq, lane);
+    }
+    if (q_ok) {
+      T* dqg = static_cast<T*>(p.dq) + (qbase + q_row) * p.dq_stride + hd * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) store_t<T>(dqg + d * 32, dq[d], p.scale, h);
+    }
+  }
+  // ---- phase 2: dK, dV (key on the lane; Q, dO in LDS) ------------------------------------------------
+  const int64_t key = w * 32 + r;
+  const bool key_in = key < lk_, key_ok = key < kvlen;
+  const bool k_wave = w * 32 < kvlen;
+  RowFrag<T, D> kf, vf;
+  if (k_wave) {
+    const int64_t kr = key_in ? key : 0;
+    kf.load(kg + kr * p.k_stride, key_in, h);              // L2 hits: the block staged these rows a moment ago
+    vf.load(vg + kr * p.v_stride, key_in, h);
+  }
+  __syncthreads();                                          // every wave is done reading K / V from LDS
+  stage2(qg, p.q_stride, dog, do_stride, lq_);
+  __syncthreads();
+  f32x16 dk[DB], dv[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
+  if (k_wave) {
+#pragma unroll
+    for (int qb = 0; qb < R / 32; ++qb) {
+      if (qb * 32 >= lq_) break;                           // block-uniform
+      f32x16 s, dp;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      mma_rows<D>(ta, PITCH, qb * 32, kf, s, r, h);
+      mma_rows<D>(tb, PITCH, qb * 32, vf, dp, r, h);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int qi = qb * 32 + acc_row(i, h);
+        const float pr = (key_ok && qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[qi])) : 0.f;
+        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        s[i] = pr * ms;
+        dp[i] = pr * (dp[i] * ms - dl_s[qi]);
+      }
+      mma_acc<D>(tb, PITCH, qb * 32, s, dv, lane);
+      mma_acc<D>(ta, PITCH, qb * 32, dp, dk, lane);
     }
   }
   if (key_in) {
@@ -752,6 +914,20 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
   p.drop_thresh = drop16(dropout_p); p.keep_scale = 65536.f / (65536.f - (float)p.drop_thresh); p.seed = seed;
+  if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && rows_k <= 128 && b * h >= 512) {
+    // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace
+    constexpr size_t kLds = (size_t)2 * 128 * (64 + 8) * sizeof(bf16_t) + 2 * 128 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+      attr_set = true;
+    }
+    if (p.drop_thresh) attn_bwd_short_kernel<64, true><<<(unsigned)(b * h), 256, kLds, st>>>(p);
+    else attn_bwd_short_kernel<64, false><<<(unsigned)(b * h), 256, kLds, st>>>(p);
+    GMLM_LAUNCH_CHECK();
+    return GMLM_OK;
+  }
   const int64_t rows = nb * lq * h;
   {
     const int cpr = (int)d / (dtype == GMLM_BF16 ? 8 : 4);
@@ -774,12 +950,18 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 2, gq, st, p);
   }
   GMLM_LAUNCH_CHECK();
-  if (pick_waves(rows_k, b * h) == 8) {
+  if (pick_waves(rows_k, b * h) == 8 && !(dtype == GMLM_F32 && d == 96)) {   // f32 d=96 at 512 threads would spill
     dim3 gk((unsigned)cdiv(rows_k, 256), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 8, gk, st, p);
-  } else if (pick_waves(rows_k, b * h) == 4) {
+  } else if (pick_waves(rows_k, b * h) >= 4) {
     dim3 gk((unsigned)cdiv(rows_k, 128), (unsigned)(b * h));
-    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
+    if (dtype == GMLM_BF16 && rows_q <= 128) {
+      // short sequences (the reference tokenises to <= 128 tokens): all query rows staged behind one barrier
+      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 128><<<gk, 256, 0, st>>>(p); }
+      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 4, false, 128><<<gk, 256, 0, st>>>(p); }
+    } else {
+      GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
+    }
   } else {
     dim3 gk((unsigned)cdiv(rows_k, 64), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
