@@ -190,6 +190,7 @@ class GraphTextLM(nn.Module):
         grad = self.plm_encoder.training or self.training
         heads = self.plm_encoder.config.num_attention_heads
         packed = (p // heads) in (64, 96) and self.plm_packed
+        plm_batch_size = max(1, min(int(plm_batch_size), 65535 // heads))   # attention grids index (sequence, head) in 16 bits
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
             weights = bert.prepare_weights(self.plm_encoder, cd)          # cast / fuse once, share across micro-batches
             for s in range(0, a, plm_batch_size):
