@@ -345,7 +345,9 @@ def main():
         model.zero_grad(set_to_none=True)
         xm = model.soft_mask_input(x, active, 0.7)
         logits = model(xm, ei, tokens, active, plm_batch_size=args.plm_batch)
-        loss = F.cross_entropy(logits[active], y[active], label_smoothing=0.2, reduction="sum") / n_active_total
+        idx = model.active_index                     # the forward's own active-node index (no second mask -> index sync)
+        loss = F.cross_entropy(logits.index_select(0, idx), y.index_select(0, idx), label_smoothing=0.2,
+                               reduction="sum") / n_active_total
         loss.backward()
         if part is not None:
             part.all_reduce_grads(model)

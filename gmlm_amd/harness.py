@@ -140,9 +140,11 @@ def train_step(model, optimizer, scheduler, x, edge_index, texts, y, active_mask
     with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
         xm = model.soft_mask_input(x, active_mask, beta)
         logits = model(xm, edge_index, texts, active_mask, edge_type=None, plm_batch_size=plm_batch_size)
-        loss = F.cross_entropy(logits[active_mask], y[active_mask], label_smoothing=label_smoothing)
+        idx = model.active_index                # ascending ids of the active nodes, built by the forward (same rows as
+        la, ya = logits.index_select(0, idx), y.index_select(0, idx)          # logits[active_mask], without its sync)
+        loss = F.cross_entropy(la, ya, label_smoothing=label_smoothing)
     with torch.no_grad():
-        acc = float((logits[active_mask].argmax(1) == y[active_mask]).float().mean())
+        acc = float((la.argmax(1) == ya).float().mean())
     if not bool(torch.isfinite(loss)):
         return StepResult(float(loss), acc, True)
     loss.backward()

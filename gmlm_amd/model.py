@@ -91,7 +91,9 @@ class GraphTextLM(nn.Module):
         self.compute_dtype = compute_dtype
         self.activation_checkpointing = activation_checkpointing
         self.plm_gradient_checkpointing = plm_gradient_checkpointing
-        self.plm_packed = True        # variable-length token packing in the text encoder (head dim 64 / 96)
+        self.plm_packed = True
+        # variable-length token packing in the text encoder (head dim 64 / 96)
+        self.active_index = None   # set by encode_texts: ascending device index of the active nodes of the last call
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
@@ -169,24 +171,46 @@ class GraphTextLM(nn.Module):
         self._tokens = {key: (tt, all_node_texts)}
         return tt
 
-    def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8) -> torch.Tensor:
+    def start_mask_copy(self, node_mask: torch.Tensor):
+        """Begin the device -> pinned-host copy of the active-node mask and mark its completion with an event.
+        The host needs the active set (count, token lengths) to lay out the packed PLM batch; waiting for THIS
+        event instead of reading the mask later means the host never waits for the GNN kernels enqueued in
+        between, and the PLM launches follow the GNN's without an idle gap (1 ms per step at Squirrel size)."""
+        if not node_mask.is_cuda:
+            return node_mask, None
+        buf = torch.empty(node_mask.numel(), dtype=torch.bool, pin_memory=True)
+        buf.copy_(node_mask.reshape(-1), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return buf, ev
+
+    def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8,
+                     _mask_copy=None) -> torch.Tensor:
         """main.py:328-358: PLM over the active nodes in micro-batches, masked mean pool, row scatter."""
         n = node_mask.numel()
         dev = node_mask.device
         p = self.plm_encoder.config.hidden_size
         plm_embeds = torch.zeros(n, p, device=dev)
-        idx = node_mask.nonzero(as_tuple=True)[0]                     # one D2H sync for the count
-        a = idx.numel()
+        mask_h, ev = _mask_copy if _mask_copy is not None else self.start_mask_copy(node_mask)
+        if ev is not None:
+            ev.synchronize()                                          # waits for the mask copy only
+        idx_h = mask_h.nonzero(as_tuple=True)[0]                      # host: ascending active node ids
+        a = idx_h.numel()
+        self.active_index = None
         if a == 0:
             return plm_embeds
+
+        def to_dev(t):                                                # pinned staging: H2D copies that do not stall the host
+            return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev)
+
+        self.active_index = to_dev(idx_h)                             # for the caller's loss gather (no mask indexing sync)
         cd = self._cd()
-        idx_h = idx.cpu()
         lens_h = tokens.lens_host[idx_h]
         # length-bucketed micro-batches: every active node is encoded independently and scattered by its own
         # index, so the order is free; sorting by token count keeps the padding of each micro-batch small
         order = torch.argsort(lens_h, descending=True, stable=True)
         lens_h = lens_h[order]
-        idx = idx[order.to(dev)]
+        idx = to_dev(idx_h[order])
         grad = self.plm_encoder.training or self.training
         heads = self.plm_encoder.config.num_attention_heads
         packed = (p // heads) in (64, 96) and self.plm_packed
@@ -204,7 +228,7 @@ class GraphTextLM(nn.Module):
                     total = int(lh.sum())
                     cu_h = torch.zeros(bi.numel() + 1, dtype=torch.int32)
                     cu_h[1:] = torch.cumsum(lh, 0)
-                    cu = cu_h.to(dev, non_blocking=True)
+                    cu = to_dev(cu_h)
                     seq = torch.repeat_interleave(torch.arange(bi.numel(), device=dev), lens.long(), output_size=total)
                     pos = torch.arange(total, device=dev) - cu[seq].long()
                     tok = tokens.input_ids[bi[seq], pos]
@@ -222,9 +246,10 @@ class GraphTextLM(nn.Module):
     def forward(self, gnn_input_features, edge_index, all_node_texts, text_processing_node_mask, edge_type=None,
                 plm_batch_size=8):
         edge_index = edge_index.to(torch.long)
+        mask_copy = self.start_mask_copy(text_processing_node_mask)                              # async; consumed below
         gnn_embeds = self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)      # fp32 [N, P]
         tokens = self.tokenize(all_node_texts)
-        plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size)       # fp32 [N, P]
+        plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy)   # fp32 [N, P]
         return self.head(gnn_embeds, plm_embeds)
 
     def head(self, gnn_embeds, plm_embeds):
