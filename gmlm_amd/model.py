@@ -185,7 +185,7 @@ class GraphTextLM(nn.Module):
         return buf, ev
 
     def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8,
-                     _mask_copy=None) -> torch.Tensor:
+                     _mask_copy=None, _weights=None) -> torch.Tensor:
         """main.py:328-358: PLM over the active nodes in micro-batches, masked mean pool, row scatter."""
         n = node_mask.numel()
         dev = node_mask.device
@@ -216,7 +216,8 @@ class GraphTextLM(nn.Module):
         packed = (p // heads) in (64, 96) and self.plm_packed
         plm_batch_size = max(1, min(int(plm_batch_size), 65535 // heads))   # attention grids index (sequence, head) in 16 bits
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
-            weights = bert.prepare_weights(self.plm_encoder, cd)          # cast / fuse once, share across micro-batches
+            # cast / fuse once, share across micro-batches (forward() has done it ahead of the GNN launches)
+            weights = _weights if _weights is not None else bert.prepare_weights(self.plm_encoder, cd)
             for s in range(0, a, plm_batch_size):
                 bi = idx[s:s + plm_batch_size]
                 lh = lens_h[s:s + plm_batch_size]
@@ -247,9 +248,12 @@ class GraphTextLM(nn.Module):
                 plm_batch_size=8):
         edge_index = edge_index.to(torch.long)
         mask_copy = self.start_mask_copy(text_processing_node_mask)                              # async; consumed below
+        # the per-step compute-dtype copy of the PLM weights does not depend on the mask: its host-side set-up
+        # (0.6 ms) runs here, under device work that is still queued, not between the GNN and the PLM launches
+        weights = bert.prepare_weights(self.plm_encoder, self._cd())
         gnn_embeds = self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)      # fp32 [N, P]
         tokens = self.tokenize(all_node_texts)
-        plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy)   # fp32 [N, P]
+        plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)   # fp32 [N, P]
         return self.head(gnn_embeds, plm_embeds)
 
     def head(self, gnn_embeds, plm_embeds):

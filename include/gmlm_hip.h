@@ -185,6 +185,9 @@ int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias
  * dropout_p > 0 drops attention probabilities (after normalisation, scaled by 1/(1-p)) exactly like
  * nn.Dropout on `attn` in main.py:161 / hf eager attention; the mask is hash(seed, (b,h,q,key)) and
  * is regenerated, not stored, by the backward pass when given the same seed.
+ * Backward: bf16, d = 64, every sequence <= 128 rows (lq, lk <= 128, or max_len <= 128 in packed mode) and
+ * b*h >= 512 runs as ONE launch per (sequence, head) (delta + dQ + dK/dV from one LDS image); everything else
+ * as three launches (delta, dQ, dK/dV).  Same results either way up to the summation order inside delta.
  * ------------------------------------------------------------------------------------------- */
 int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                        int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
