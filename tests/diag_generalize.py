@@ -1,6 +1,11 @@
-"""Diagnostic: does training with dropout ON generalise like training with dropout OFF (same init, same masks)?"""
+"""Diagnostic (not a test; run by hand on the GPU box: python tests/diag_generalize.py): does training with dropout ON
+generalise like training with dropout OFF (same init, same masks)?  Lives under tests/ because it uses the oracle's
+synthetic-input helpers, which only test code may import."""
 import sys, numpy as np, torch, torch.nn.functional as F
-sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for d in ("tests", "oracle", ""):
+    sys.path.insert(0, os.path.join(ROOT, d))
 import gmlm_oracle as O
 from helpers import model_state_template
 from param_recipe import recipe_state_dict

@@ -143,7 +143,7 @@ def test_bf16_training_reduces_loss_on_learnable_labels():
         losses.append(r.loss)
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
     # eval mode (dropout off, no soft mask) on the nodes it was trained on: the labels have been fitted.  Held-out
-    # accuracy is NOT asserted: on this random graph it depends on the init (tools/diag_generalize.py: 0.24-0.92
+    # accuracy is NOT asserted: on this random graph it depends on the init (tests/diag_generalize.py: 0.24-0.92
     # for the same protocol, and the CPU oracle gives the same 40-step trajectory as the fp32 path to 3 decimals).
     loss, acc, f1 = harness.eval_step(m, xd, eid, tokens, yd, td, plm_batch_size=4096)
     assert np.isfinite(loss) and acc > 0.8 and f1 > 0.8
