@@ -252,10 +252,32 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv;
   const int64_t nwaves = (int64_t)gridDim.x * 4;
   const float inv_f = 1.f / (float)f;
+  // the loads of row group t+1 are issued before the arithmetic of row group t (two row groups in flight per wave)
+  struct RowIn { uint4 x[CH], g[CH], rr[CH]; float mu, rs; };
+  auto fetch = [&](int64_t r0, RowIn& in) {
+    const int64_t r = r0 + sub;
+    const bool live = r < rows;
+    in.mu = live ? mean[r] : 0.f;
+    in.rs = live ? rstd[r] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int ch = c * LPR + lr;
+      if (ch < nch && live) {
+        const int64_t off = r * f + (int64_t)ch * V;
+        in.x[c] = *reinterpret_cast<const uint4*>(x + off);
+        in.g[c] = *reinterpret_cast<const uint4*>(dy + off);
+        if (RES) in.rr[c] = *reinterpret_cast<const uint4*>(res + off);
+      }
+    }
+  };
+  RowIn cur;
+  if (wave0 * RPW < rows) fetch(wave0 * RPW, cur);
   for (int64_t r0 = wave0 * RPW; r0 < rows; r0 += nwaves * RPW) {
     const int64_t r = r0 + sub;
     const bool live = r < rows;
-    const float mu = live ? mean[r] : 0.f, rs = live ? rstd[r] : 0.f;
+    RowIn nxt;
+    if (r0 + nwaves * RPW < rows) fetch(r0 + nwaves * RPW, nxt);
+    const float mu = cur.mu, rs = cur.rs;
     float zh[CH][V], dzh[CH][V];
     float s1 = 0.f, s2 = 0.f;
     uint32_t keep = 0;                       // dropout decisions of this lane's elements, reused by the dx pass
@@ -265,9 +287,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       if (ch < nch && live) {
         const int64_t off = r * f + (int64_t)ch * V;
         float gv[V], rr[V];
-        Store<T>::ldv(x + off, zh[c]);
-        Store<T>::ldv(dy + off, gv);
-        if (RES) Store<T>::ldv(res + off, rr);
+        Store<T>::unpack(cur.x[c], zh[c]);
+        Store<T>::unpack(cur.g[c], gv);
+        if (RES) Store<T>::unpack(cur.rr[c], rr);
         uint32_t kb = 0;
         if (DROP) {
           kb = dropout_keep_bits<V>(seed, (uint64_t)off, thresh);
@@ -308,6 +330,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         if (dres) Store<T>::stv(dres + off, dz);
       }
     }
+    cur = nxt;
   }
   // block reduction: the two row groups of a wave (LPR = 32) first add up by shuffle, then the 4 waves
   // through LDS (slot = wave), column-wise in a fixed order
