@@ -668,9 +668,7 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
   const T* og = static_cast<const T*>(p.out) + (qbase * p.h + hd) * D;
   const int64_t do_stride = p.h * D;
   // two tiles at a time through the same LDS image; only the 32-row blocks the sequence touches are written
-  auto stage2 = [&](const T* ga, int64_t sa, const T* gb, int64_t sb, int64_t len) {
-    const int need = (int)((len + 31) / 32) * 32;
-    uint4 a[PER], c[PER];
+  auto load2 = [&](const T* ga, int64_t sa, const T* gb, int64_t sb, int64_t len, uint4 (&a)[PER], uint4 (&c)[PER]) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
@@ -681,6 +679,9 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
         c[k] = *reinterpret_cast<const uint4*>(gb + row * sb + col);
       }
     }
+  };
+  auto store2 = [&](const uint4 (&a)[PER], const uint4 (&c)[PER], int64_t len) {
+    const int need = (int)((len + 31) / 32) * 32;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
@@ -690,9 +691,12 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
       }
     }
   };
-  stage2(kg, p.k_stride, vg, p.v_stride, lk_);
+  uint4 ra[PER], rc[PER];
+  load2(kg, p.k_stride, vg, p.v_stride, lk_, ra, rc);
+  store2(ra, rc, lk_);
   const float sl2 = p.scale * kLog2e;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
+  const int kvl = (int)kvlen;                               // <= 128: 32-bit index arithmetic below
   // ---- phase 1: dQ (query on the lane; K, V in LDS) ---------------------------------------------------
   const int64_t q_row = w * 32 + r;
   const bool q_ok = q_row < lq_;
@@ -710,10 +714,11 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl = fmaf((float)dof.v[s][j], (float)of.v[s][j], dl);
     dl = xhalf_sum(dl);
-    lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : 0.f;
-    if (h == 0) { lse_s[q_row] = lse2; dl_s[q_row] = dl; }
+    lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : INFINITY;   // +inf: a row past the sequence gets probability 0
+    if (h == 0) { lse_s[q_row] = lse2; dl_s[q_row] = q_ok ? dl : 0.f; }
   }
   __syncthreads();
+  load2(qg, p.q_stride, dog, do_stride, lq_, ra, rc);     // Q / dO for phase 2: in flight under the phase-1 MFMAs
   if (q_wave) {
     const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
     f32x16 dq[DB];
@@ -729,11 +734,15 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
       mma_rows<D>(ta, PITCH, kb * 32, qf, s, r, h);
       mma_rows<D>(tb, PITCH, kb * 32, dof, dp, r, h);
+      const bool full = (kb + 1) * 32 <= kvl;               // block-uniform: no per-key masking inside the block
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t key = kb * 32 + acc_row(i, h);
-        const float pr = (key < kvlen && q_ok) ? fast_exp2(fmaf(s[i], sl2, -lse2)) : 0.f;
-        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        const int key = kb * 32 + acc_row(i, h);
+        // masked scores get exponent -inf (probability exactly 0) through a select, not a branch around the exp
+        float arg = fmaf(s[i], sl2, -lse2);
+        if (!full) arg = key < kvl ? arg : -INFINITY;
+        const float pr = fast_exp2(arg);
+        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), key & 1, p.drop_thresh, p.keep_scale) : 1.f;
         s[i] = pr * (dp[i] * ms - dl);
       }
       mma_acc<D>(ta, PITCH, kb * 32, s, dq, lane);
@@ -755,7 +764,7 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
     vf.load(vg + kr * p.v_stride, key_in, h);
   }
   __syncthreads();                                          // every wave is done reading K / V from LDS
-  stage2(qg, p.q_stride, dog, do_stride, lq_);
+  store2(ra, rc, lq_);
   __syncthreads();
   f32x16 dk[DB], dv[DB];
 #pragma unroll
@@ -772,12 +781,20 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
       mma_rows<D>(ta, PITCH, qb * 32, kf, s, r, h);
       mma_rows<D>(tb, PITCH, qb * 32, vf, dp, r, h);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int qi = qb * 32 + acc_row(i, h);
-        const float pr = (key_ok && qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[qi])) : 0.f;
-        const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
-        s[i] = pr * ms;
-        dp[i] = pr * (dp[i] * ms - dl_s[qi]);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int q4 = qb * 32 + 8 * g4 + 4 * h;           // accumulator registers 4*g4 .. 4*g4+3 = queries q4 .. q4+3
+        const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q4);
+        const float4 d4 = *reinterpret_cast<const float4*>(dl_s + q4);
+        const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int i = 4 * g4 + j, qi = q4 + j;
+          // rows past the sequence carry lse = +inf in LDS (exponent -inf -> probability 0); masked keys likewise
+          const float pr = fast_exp2(key_ok ? fmaf(s[i], sl2, -lq4[j]) : -INFINITY);
+          const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+          s[i] = pr * ms;
+          dp[i] = pr * (dp[i] * ms - dq4[j]);
+        }
       }
       mma_acc<D>(tb, PITCH, qb * 32, s, dv, lane);
       mma_acc<D>(ta, PITCH, qb * 32, dp, dk, lane);
