@@ -442,8 +442,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   qf.load(static_cast<const T*>(p.q) + (qbase + qr) * p.q_stride + hd * D, q_ok, h);
   dof.load(static_cast<const T*>(p.dout) + ((qbase + qr) * p.h + hd) * D, q_ok, h);
   const float sl2 = p.scale * kLog2e;
-  const float lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : 0.f;
+  const float lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : INFINITY;
   const float dl = q_ok ? p.delta[lse_base + q_row] : 0.f;
+  const int kvl = (int)(kvlen < (1 << 30) ? kvlen : (1 << 30));
   const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   f32x16 dq[DB];
@@ -478,11 +479,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
       mma_rows<D>(ks[cur], PITCH, kb * 32, qf, s, r, h);
       mma_rows<D>(vs[cur], PITCH, kb * 32, dof, dp, r, h);
+      const bool full = kv0 + (kb + 1) * 32 <= kvlen;          // block-uniform
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int64_t key = kv0 + kb * 32 + acc_row(i, h);
-        const float pr = (key < kvlen && q_ok) ? fast_exp2(fmaf(s[i], sl2, -lse2)) : 0.f;
-        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+        const int key = (int)kv0 + kb * 32 + acc_row(i, h);
+        // a masked key gets exponent -inf through a select (no branch around the exp); whole blocks skip the test;
+        // a query row past the sequence has lse = +inf, i.e. probability 0 everywhere
+        float arg = fmaf(s[i], sl2, -lse2);
+        if (!full) arg = key < kvl ? arg : -INFINITY;
+        const float pr = fast_exp2(arg);
+        const float ms = DROP ? drop_mul16(drop_word(seed32, qmix, (uint32_t)(key >> 1)), key & 1, p.drop_thresh, p.keep_scale) : 1.f;
         s[i] = pr * (dp[i] * ms - dl);
       }
       mma_acc<D>(ks[cur], PITCH, kb * 32, s, dq, lane);
@@ -524,8 +530,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   constexpr int NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
   __shared__ __attribute__((aligned(16))) T qs[NBUF][QT * PITCH];
   __shared__ __attribute__((aligned(16))) T dos[NBUF][QT * PITCH];
-  __shared__ float lse_s[NBUF][QT];
-  __shared__ float dl_s[NBUF][QT];
+  __shared__ __attribute__((aligned(16))) float lse_s[NBUF][QT];
+  __shared__ __attribute__((aligned(16))) float dl_s[NBUF][QT];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
   int64_t lq_, lk_, qbase, kbase, lse_base;
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
     auto load_small = [&](int64_t q0) {
       if (tid < QT) {
         const bool ok = q0 + tid < lq_;
-        lr = ok ? lse_g[q0 + tid] * kLog2e : 0.f;
+        lr = ok ? lse_g[q0 + tid] * kLog2e : INFINITY;     // +inf: probability 0 for a row past the sequence
         dr = ok ? dl_g[q0 + tid] : 0.f;
       }
     };
@@ -598,12 +604,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         mma_rows<D>(qs[cur], PITCH, qb * 32, kf, s, r, h);
         mma_rows<D>(dos[cur], PITCH, qb * 32, vf, dp, r, h);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int qi = qb * 32 + acc_row(i, h);
-          const float pr = (key_ok && q0 + qi < lq_) ? fast_exp2(fmaf(s[i], sl2, -lse_s[cur][qi])) : 0.f;
-          const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
-          s[i] = pr * ms;
-          dp[i] = pr * (dp[i] * ms - dl_s[cur][qi]);
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int q4 = qb * 32 + 8 * g4 + 4 * h;       // accumulator registers 4*g4 .. 4*g4+3 = queries q4 .. q4+3
+          const float4 l4 = *reinterpret_cast<const float4*>(&lse_s[cur][q4]);
+          const float4 d4 = *reinterpret_cast<const float4*>(&dl_s[cur][q4]);
+          const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv4[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = 4 * g4 + j, qi = q4 + j;
+            // query rows past the sequence carry lse = +inf in LDS, masked keys select the exponent -inf: both give
+            // probability exactly 0 without a branch around the exp
+            const float pr = fast_exp2(key_ok ? fmaf(s[i], sl2, -lv[j]) : -INFINITY);
+            const float ms = DROP ? drop_mul16(drop_word(seed32, (uint32_t)(lse_base + q0 + qi) * 0x9E3779B1u, (uint32_t)(key >> 1)), (int)(key & 1), p.drop_thresh, p.keep_scale) : 1.f;
+            s[i] = pr * ms;
+            dp[i] = pr * (dp[i] * ms - dv4[j]);
+          }
         }
         mma_acc<D>(dos[cur], PITCH, qb * 32, s, dv, lane);
         mma_acc<D>(qs[cur], PITCH, qb * 32, dp, dk, lane);
