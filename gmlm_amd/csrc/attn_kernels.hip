@@ -526,7 +526,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
 // 16-128 tokens the per-tile barrier / LDS round trip, not the MFMA work, sets the block's lifetime).
 template <typename T, int D, int NW, bool DROP, int QT = 32>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
-  constexpr bool DBUF = sizeof(T) == 2 && QT == 32;
+  constexpr bool DBUF = sizeof(T) == 2 && QT <= 64;
   constexpr int NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
   __shared__ __attribute__((aligned(16))) T qs[NBUF][QT * PITCH];
   __shared__ __attribute__((aligned(16))) T dos[NBUF][QT * PITCH];
@@ -984,7 +984,12 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   GMLM_LAUNCH_CHECK();
   if (pick_waves(rows_k, b * h) == 8 && !(dtype == GMLM_F32 && d == 96)) {   // f32 d=96 at 512 threads would spill
     dim3 gk((unsigned)cdiv(rows_k, 256), (unsigned)(b * h));
-    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 8, gk, st, p);
+    if (dtype == GMLM_BF16) {   // long sequences: 64 query rows per barrier (two 32-row blocks), double-buffered
+      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 8, true, 64><<<gk, 512, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 8, false, 64><<<gk, 512, 0, st>>>(p); }
+      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 8, true, 64><<<gk, 512, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 8, false, 64><<<gk, 512, 0, st>>>(p); }
+    } else {
+      GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 8, gk, st, p);
+    }
   } else if (pick_waves(rows_k, b * h) >= 4) {
     dim3 gk((unsigned)cdiv(rows_k, 128), (unsigned)(b * h));
     if (dtype == GMLM_BF16 && rows_q <= 128) {
