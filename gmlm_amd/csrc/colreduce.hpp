@@ -2,7 +2,7 @@
 //   out[k][c] = sum_i fn(i, c)[k],  k < K
 // Pass 1: block (column tile of 64, row chunk) -> partial[chunk][k][c]; each wave reads 64
 // consecutive elements of one row per step (coalesced), 4 rows in flight per block.
-// Pass 2: partial chunks summed in chunk order.  No atomics => bitwise reproducible.
+// Pass 2: partial chunks summed in a fixed order (rows_sum_kernel).  No atomics => bitwise reproducible.
 #pragma once
 #include "common.hpp"
 
@@ -62,23 +62,10 @@ __global__ __launch_bounds__(256) void col_reduce_partial_kernel(int64_t n, int6
   }
 }
 
-template <int K>
-__global__ void col_reduce_final_kernel(const float* __restrict__ partial, int chunks, int64_t f, float* __restrict__ out,
-                                        float scale) {
-  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= f) return;
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    float s = 0.f;
-    for (int j = 0; j < chunks; ++j) s += partial[((int64_t)j * K + k) * f + c];
-    out[(int64_t)k * f + c] = s * scale;
-  }
-}
-
 // out[c] = sum_r partial[r][c] for a small [nrows, width] fp32 matrix: block = 32 columns x 8 row lanes,
 // independent loads in flight, fixed-order LDS tree (deterministic).
 static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __restrict__ partial, int nrows, int64_t width,
-                                                        float* __restrict__ out) {
+                                                        float* __restrict__ out, float scale = 1.f) {
   __shared__ float red[8][32];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int64_t c = (int64_t)blockIdx.x * 32 + tx;
@@ -95,7 +82,7 @@ static __global__ __launch_bounds__(256) void rows_sum_kernel(const float* __res
   red[ty][tx] = acc;
   __syncthreads();
   if (ty == 0 && c < width)
-    out[c] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
+    out[c] = (((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]))) * scale;
 }
 
 // out: [K, f] (k-major).  Returns a gmlm status.
@@ -116,7 +103,9 @@ int col_reduce(int64_t n, int64_t f, Fn fn, float* out, void* workspace, size_t 
   float* partial = static_cast<float*>(workspace);
   col_reduce_partial_kernel<K, Fn><<<dim3(p.col_tiles, p.chunks), 256, 0, st>>>(n, f, p.rows_per_chunk, fn, partial);
   GMLM_LAUNCH_CHECK();
-  col_reduce_final_kernel<K><<<(int)cdiv(f, 256), 256, 0, st>>>(partial, p.chunks, f, out, scale);
+  // second pass: the partial rows are [chunks][K*f] and the result [K][f] has the same column order, so this is a plain
+  // row sum with 8 row lanes x 4 loads in flight (one thread per column walking all chunks serially took 150 us at f = 768)
+  rows_sum_kernel<<<(unsigned)cdiv((int64_t)K * f, 32), 256, 0, st>>>(partial, p.chunks, (int64_t)K * f, out, scale);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }
