@@ -22,7 +22,7 @@ SIGNATURES = {
     "gmlm_device_check": (C.c_int, [_p, _p, C.c_char_p, _i32]),
     "gmlm_degree_i32": (C.c_int, [_p, _i64, _i64, _p, _p]),
     "gmlm_degree_f32": (C.c_int, [_p, _i64, _i64, _p, _p]),
-    "gmlm_edge_bucket": (C.c_int, [_p, _p, _i64, _p, _p]),
+    "gmlm_edge_bucket": (C.c_int, [_p, _p, _i64, _i64, _p, _p]),
     "gmlm_relation_histogram": (C.c_int, [_p, _i64, _i32, _p, _p]),
     "gmlm_segment_sort_workspace_bytes": (_sz, [_i64]),
     "gmlm_segment_sort": (C.c_int, [_p, _p, _p, _i32, _i64, _i64, _p, _p, _p, _p, _p, _sz, _p]),

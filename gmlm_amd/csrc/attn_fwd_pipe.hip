@@ -1,0 +1,438 @@
+// K5/K7 forward, bf16: software-pipelined streaming-softmax attention for gfx950.
+// Reference: BertSelfAttention's softmax(QK^T*d^-1/2 + padding mask)V (hf:modeling_bert.py:188-201) and
+// CrossAttention.forward's dense [1,8,N,N] softmax (main.py:159-163).
+//
+// Same data orientation as attn_fwd_kernel (attn_kernels.hip): S^T = K Q^T so that the query sits on the lane and the
+// keys in the accumulator registers; P feeds O^T += V^T P^T from registers; V^T through ds_read_b64_tr_b16.
+// What is different:
+//  * schedule.  The unit of work is 32 keys (one 32x32 score block).  At step u a wave issues, in ONE basic block,
+//        check(u):            wave vote "does block u exceed the reference max by more than 2^kDefer" (8 v_max3 + vote)
+//        QK(u+1) and PV(u-1): 1 + D/16 + 2*D/32 MFMAs
+//        SM(u):               exp2 / row sum / bf16 packing of block u -- one probability pair per MFMA gap
+//    hand-interleaved (one MFMA per gap, fenced by sched_barrier(0)), so the matrix pipe works on the neighbouring
+//    blocks while the VALU does the softmax of this one: the two pipes overlap INSIDE a wave.
+//  * softmax arithmetic per score = v_exp + v_add (+ half a v_cvt_pk, half a v_max3).  Q is pre-multiplied by
+//    scale * log2(e), and the reference max rides in the contraction: one extra MFMA k-step with a constant
+//    [1 0 .. 0] fragment against [-m 0 .. 0]^T, so scores leave the MFMA chain already max-subtracted (m is kept
+//    bf16-representable, the product is exact).  The rescale is deferred (guide T13) and, when it fires, O is scaled
+//    AFTER the pending PV(u-1) has been accumulated: everything summed so far is at the old scale exactly once.
+//  * staging.  K/V tiles (64 keys) arrive by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) into XOR-swizzled
+//    images whose operand reads are bank-conflict free; the DMA pieces ride in the MFMA gaps.  K is consumed one
+//    tile ahead of V, so two buffers each need ONE workgroup barrier per tile.
+// Measured (MI355X, h = 8, d = 96, N = 20,804): 1.95 ms -> 1.59 ms against attn_fwd_kernel; what each step bought and
+// what did not pay (3-deep LDS ring, wave stagger, compiler-tracked DMA builtin) is in DESIGN.md section 5.
+#include "attn_common.hpp"
+
+namespace gmlm {
+
+__device__ __forceinline__ float max16(const f32x16& s) {
+  float a = fmaxf(fmaxf(s[0], s[1]), s[2]);
+  float b = fmaxf(fmaxf(s[3], s[4]), s[5]);
+  a = fmaxf(fmaxf(a, s[6]), s[7]);
+  b = fmaxf(fmaxf(b, s[8]), s[9]);
+  a = fmaxf(fmaxf(a, s[10]), s[11]);
+  b = fmaxf(fmaxf(b, s[12]), s[13]);
+  a = fmaxf(fmaxf(a, s[14]), s[15]);
+  return fmaxf(a, b);
+}
+
+// round-to-nearest bf16 value of x, as f32
+__device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
+
+// ---- LDS images of a 64-row K / V tile, filled by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B = 1 KiB of
+// CONTIGUOUS LDS per wave-instruction, per-lane source address) --------------------------------------------------
+// Rows are RP = 128 B (d = 64) or 256 B (d = 96: 12 real 16-byte chunks + 4 filler chunks, so that a row spans all
+// 64 banks) with no padding; bank conflicts are avoided by an XOR on the chunk index applied through the SOURCE
+// address (chunk c of row r is stored in slot c ^ f(r)) and again on the read (guide rule 21):
+//   K image, read as MFMA A-operand rows (ds_read_b128, 16 lanes = 16 different rows, same chunk):
+//       d = 64: f = (r >> 1) & 7 (with the row parity that is 16 distinct 16-byte slots);  d = 96: f = r & 15
+//   V image, read through ds_read_b64_tr_b16 (a half-wave = 4 rows x 64 contiguous bytes):
+//       d = 64: f = 4 * ((r >> 1) & 1);  d = 96: f = 4 * (r & 3)   -> the four rows land in four different bank quarters
+template <int D> struct Img {
+  static constexpr int RP = D == 64 ? 128 : 256;        // row pitch, bytes
+  static constexpr int CPR = RP / 16;                   // 16-byte slots per row
+  static constexpr int TILE = 64 * RP;                  // bytes per 64-row tile
+  static constexpr int NDMA = TILE / 1024;              // wave-instructions per tile
+  __device__ static __forceinline__ int fk(int r) { return D == 64 ? ((r >> 1) & 7) : (r & 15); }
+  __device__ static __forceinline__ int fv(int r) { return D == 64 ? 4 * ((r >> 1) & 1) : 4 * (r & 3); }
+};
+
+// this wave's share of the DMA instructions of one tile: instruction I = w + NW * k writes LDS bytes [1024 I, 1024 I + 1024)
+template <int D, int NW, bool ISV>
+struct DmaPlan {
+  using G = Img<D>;
+  static constexpr int PER = G::NDMA / NW;
+  int goff[PER];    // element offset of this lane's source chunk inside a tile: row * stride + 8 * chunk
+  int rowk[PER];    // tile row of the chunk
+  int colk[PER];    // 8 * chunk
+  __device__ __forceinline__ void init(int64_t g_stride, int w, int lane) {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int idx = 64 * (w + NW * k) + lane, row = idx / G::CPR, slot = idx % G::CPR;
+      int chunk = slot ^ (ISV ? G::fv(row) : G::fk(row));
+      if (chunk >= D / 8) chunk = D / 8 - 1;            // filler slots of the d = 96 image: any valid address
+      rowk[k] = row; colk[k] = 8 * chunk;
+      goff[k] = (int)(row * g_stride) + 8 * chunk;
+    }
+  }
+  // g: start of the (batch, head) slab; row0: first row of the tile; limit: rows of the slab (>= 1).  Rows past the
+  // slab re-read its last row (finite data; their scores are masked / their probabilities are exactly 0).
+  __device__ __forceinline__ void piece(int k, const bf16_t* g, int64_t g_stride, int64_t row0, int64_t limit, uint32_t tile /* LDS byte address */, int w) const {
+    const bf16_t* base = g + row0 * g_stride;           // wave-uniform
+    const int left = (int)(limit - row0 < (1 << 29) ? limit - row0 : (1 << 29));
+    const bf16_t* src = base + (left >= 64 || rowk[k] < left ? goff[k] : (int)((left - 1) * g_stride) + colk[k]);
+    // Inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read it cannot prove disjoint
+    // (s_waitcnt vmcnt(0) right behind the DMA), which exposes the whole load latency.  The asm form is invisible
+    // to that bookkeeping; the kernel waits for its DMA itself (dma_wait() ahead of the barrier that publishes the
+    // tile).  M0 = LDS base of the piece, saved / restored around the instruction (guide 5.7, glds16 recipe).
+    const uint32_t dst_u = __builtin_amdgcn_readfirstlane(tile + 1024u * (uint32_t)(w + NW * k));
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst_u) : "memory");
+  }
+  __device__ __forceinline__ void issue(const bf16_t* g, int64_t g_stride, int64_t row0, int64_t limit, uint32_t tile /* LDS byte address */, int w) const {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) piece(k, g, g_stride, row0, limit, tile, w);
+  }
+};
+
+// all LDS-DMA pieces this wave has issued have landed (vmcnt also counts ordinary loads / stores: none are pending in the loop)
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int D, int NW, bool DROP, int NB>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
+  using T = bf16_t;
+  using G = Img<D>;
+  constexpr int KT = 64, DB = D / 32, NQ = D / 16, NP = 2 * DB, NM = NQ + 1 + NP, RP = G::RP;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];      // K ring [NB][TILE], then V ring [NB][TILE]
+  unsigned char (*ks)[G::TILE] = reinterpret_cast<unsigned char (*)[G::TILE]>(smem_dyn);
+  unsigned char (*vs)[G::TILE] = reinterpret_cast<unsigned char (*)[G::TILE]>(smem_dyn + NB * G::TILE);
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  if ((int64_t)blockIdx.x * (NW * 32) >= lq_) return;            // varlen: tile past this sequence (block-uniform)
+  const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
+  const bool q_ok = q_row < lq_;
+  // a wave whose 32 queries all lie past the sequence (short packed sequences) only helps staging K/V
+  const bool wave_live = (int64_t)blockIdx.x * (NW * 32) + w * 32 < lq_;
+  int64_t kvlen64 = lk_;
+  if (p.kv_len) { kvlen64 = p.kv_len[b]; if (kvlen64 > lk_) kvlen64 = lk_; if (kvlen64 < 0) kvlen64 = 0; }
+  const int kvlen = (int)(kvlen64 < (1 << 30) ? kvlen64 : (1 << 30));
+  const T* qg = static_cast<const T*>(p.q) + (qbase + (q_ok ? q_row : 0)) * p.q_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
+  // Q' = bf16(Q * scale * log2 e): scores leave the MFMA in the log2 domain (one more bf16 rounding of q, the size of
+  // the rounding q already carries).  The extra contraction step [1 0 .. 0] x [-m 0 .. 0]^T subtracts the reference
+  // max m (kept bf16-representable, so the product is exact) inside the MFMA chain: p = exp2(s') needs no fma.
+  RowFrag<T, D> qf;
+  qf.load(qg, q_ok, h);
+  const float sl2 = p.scale * kLog2e;
+#pragma unroll
+  for (int s = 0; s < NQ; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf.v[s][j] = (__bf16)((float)qf.v[s][j] * sl2);
+  bf16x8 ones, qx;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)0.f; qx[j] = (__bf16)0.f; }
+  if (h == 0) ones[0] = (__bf16)1.f;
+  f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float m = 0.f, l = 0.f;      // reference max (log2 domain, bf16-representable, identical in both half-waves) / this half-wave's partial row sum
+  const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
+  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
+  const int nunits = (kvlen + 31) >> 5;       // 32-key score blocks that hold at least one valid key
+  const int ntiles = (nunits + 1) >> 1;
+  const int last_valid = kvlen - 32 * (nunits - 1);   // valid keys of the last block (1..32)
+  // lane constants of the LDS operand reads (byte offsets inside a tile image)
+  int koff[NQ];                                         // K A-operand, contraction step s: row r, chunk 2s + h
+#pragma unroll
+  for (int s = 0; s < NQ; ++s) koff[s] = r * RP + (((2 * s + h) ^ G::fk(r)) << 4);
+  int voff[DB];                                         // V^T A-operand, d-block db: row 4*(lane>>5) + qq, chunk 4 db + 2 g1 + (pp >> 1)
+  {
+    const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1, row = 4 * (lane >> 5) + qq;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) voff[db] = row * RP + (((4 * db + 2 * g1 + (pp >> 1)) ^ G::fv(row)) << 4) + 8 * (pp & 1);
+  }
+  auto kfrag = [&](const unsigned char* tile, int row0, int s) {
+    return *reinterpret_cast<const bf16x8*>(tile + row0 * RP + koff[s]);
+  };
+  auto vfrag = [&](const unsigned char* tile, int row0, int j, bf16x4& lo, bf16x4& hi) {   // PV MFMA j: k-step j / DB, d-block j % DB
+    const unsigned char* a = tile + (row0 + 16 * (j / DB)) * RP + voff[j % DB];
+    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, a));
+    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, a + 8 * RP));
+  };
+
+  // probabilities of scores 2j, 2j+1 of block u: exp2, partial row sum, (dropout), bf16 pair
+  auto sm_pair = [&](const f32x16& sc, bf16x8 (&pc)[2], int u, int j, float& rs0, float& rs1) {
+    const int i = 2 * j;
+    const float e0 = fast_exp2(sc[i]);                               // masked: exp2(-inf) = 0
+    const float e1 = fast_exp2(sc[i + 1]);
+    rs0 += e0;                                                       // the normaliser uses the un-dropped probabilities
+    rs1 += e1;
+    float d0 = e0, d1 = e1;
+    if (DROP) {
+      const uint32_t wd = drop_word(seed32, qmix, (uint32_t)((32 * u + acc_row(i, h)) >> 1));
+      d0 = e0 * drop_mul16(wd, 0, p.drop_thresh, p.keep_scale);
+      d1 = e1 * drop_mul16(wd, 1, p.drop_thresh, p.keep_scale);
+    }
+    pc[i >> 3][i & 7] = (__bf16)d0;
+    pc[i >> 3][(i & 7) + 1] = (__bf16)d1;
+  };
+  auto softmax_block = [&](const f32x16& sc, bf16x8 (&pc)[2], int u) {
+    float rs0 = 0.f, rs1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm_pair(sc, pc, u, j, rs0, rs1);
+    l += rs0 + rs1;
+  };
+  // S'^T(block) = K(rows row0..row0+31) Q'^T - m: the max column first, then the D/16 real contraction steps
+  auto qk_unit = [&](const unsigned char* tile, int row0, f32x16& s) {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qx, z, 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(tile, row0, t), qf.v[t], s, 0, 0, 0);
+  };
+  // O^T[db] += V^T(tile rows row0..row0+31) * P^T, P packed to bf16 in accumulator order (k-step s = regs 8s..8s+7)
+  auto pv_unit = [&](const unsigned char* tile, int row0, const bf16x8 (&pk)[2]) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      bf16x4 lo, hi;
+      vfrag(tile, row0, j, lo, hi);
+      bf16x8 a;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { a[t] = lo[t]; a[4 + t] = hi[t]; }
+      o[j % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[j / DB], o[j % DB], 0, 0, 0);
+    }
+  };
+  // block u against the reference max: the common case is a wave vote on "no score exceeds m by 2^kDefer" (each
+  // half-wave looks at its own 16 keys: no exchange needed for a wave-uniform decision).  Otherwise (first block,
+  // or a real jump) the reference moves to the bf16-rounded row max: s' -= delta, l *= alpha now; O *= alpha after
+  // the pending PV(u-1) has been accumulated, so that everything summed so far is at the old scale exactly once
+  // (guide T13 hazard).  Returns alpha (1 when nothing moved).
+  auto check = [&](f32x16& sc, int u, bool& rare) {
+    if (u == nunits - 1 && last_valid < 32) {           // only the last block can hold masked keys (wave-uniform)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[i] = acc_row(i, h) < last_valid ? sc[i] : -INFINITY;
+    }
+    const float g = max16(sc);
+    rare = u == 0 || !__all(g <= kDefer);
+    float alpha = 1.f;
+    if (rare) {
+      const float gr = xhalf_max(g);                    // finite: the first key of every block is valid
+      float m_new = bf16_round(m + gr);
+      if (u != 0) m_new = fmaxf(m, m_new);              // only ever raised after the first block
+      const float delta = m_new - m;
+      alpha = u == 0 ? 1.f : fast_exp2(-delta);         // first block: O = l = 0, nothing to scale (and -delta may be huge)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sc[i] -= delta;
+      l *= alpha;
+      m = m_new;
+      qx[0] = h == 0 ? (__bf16)(-m_new) : (__bf16)0.f;
+    }
+    return alpha;
+  };
+  auto scale_o = [&](float alpha) {
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
+  };
+
+  // ---- generic step (prologue / tail): same work, no interleave ------------------------------------------------
+  //  sc: scores of block u (log2 domain, reference max subtracted)   pc: packed probabilities of block u (output)
+  //  sn: receives the scores of block u+1                              pp: packed probabilities of block u-1
+  auto step = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u, bool has_pv, bool has_qk,
+                  const unsigned char* vprev, int vrow0, const unsigned char* knext, int krow0) {
+    bool rare;
+    const float alpha = check(sc, u, rare);
+    if (has_pv) pv_unit(vprev, vrow0, pp);
+    if (has_qk) qk_unit(knext, krow0, sn);
+    softmax_block(sc, pc, u);
+    if (rare) scale_o(alpha);
+  };
+  // ---- steady-state step: PV(u-1) and QK(u+1) on the matrix pipe under the softmax of block u ---------------
+  auto step_full = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u,
+                       const unsigned char* vprev, int vrow0, const unsigned char* knext, int krow0, auto&& gap_hook) {
+    // operand reads of the first MFMAs go out before the check: its ~15 VALU instructions cover their latency
+    bf16x8 ka[NQ];
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) ka[s] = kfrag(knext, krow0, s);
+    bf16x4 vlo[NP], vhi[NP];
+    constexpr int LA = 3;                               // PV operand reads run LA gaps ahead of their MFMA
+    bool rare;
+    const float alpha = check(sc, u, rare);
+    // hand-placed: one MFMA per gap, the operand reads of a later MFMA, one probability pair;
+    // sched_barrier(0) keeps every gap's instructions inside the gap
+    float rs0 = 0.f, rs1 = 0.f;
+    int pair = 0;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NM; ++g) {
+      if (g == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) z[i] = 0.f;
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qx, z, 0, 0, 0);
+      } else if (g <= NQ) {
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[g - 1], qf.v[g - 1], sn, 0, 0, 0);
+      } else {
+        const int j = g - NQ - 1;
+        bf16x8 a;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { a[t] = vlo[j][t]; a[4 + t] = vhi[j][t]; }
+        o[j % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pp[j / DB], o[j % DB], 0, 0, 0);
+      }
+      {
+        const int j = g + LA - NQ - 1;                  // PV MFMA whose operands are fetched in this gap
+        if (j >= 0 && j < NP) vfrag(vprev, vrow0, j, vlo[j], vhi[j]);
+      }
+      gap_hook(g);
+      if (pair < 8 && (NM <= 9 || (g % 3) != 2)) { sm_pair(sc, pc, u, pair, rs0, rs1); ++pair; }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // pin the probabilities inside this basic block (their consumers are in later blocks: without a use here the
+    // compiler sinks the whole softmax below the MFMAs, past the branch that follows)
+    asm volatile("" : "+v"(pc[0]), "+v"(pc[1]), "+v"(rs0), "+v"(rs1));
+    l += rs0 + rs1;
+    if (rare) scale_o(alpha);
+  };
+
+#ifdef GMLM_ATTN_STAMP
+  uint64_t t_steps = 0, t_stage = 0, t_bar = 0, t_load = 0, t0_, t1_, t2_, t3_, t4_;
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(x)
+#endif
+  // LDS byte addresses of the tile buffers (the DMA destination goes through M0)
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem_dyn;
+  auto ks_a = [&](int t) { return lds0 + (uint32_t)((t % NB) * G::TILE); };                 // LDS address of K tile t's buffer
+  auto vs_a = [&](int t) { return lds0 + (uint32_t)((NB + t % NB) * G::TILE); };
+  DmaPlan<D, NW, false> kd;
+  DmaPlan<D, NW, true> vd;
+  kd.init(p.k_stride, w, lane);
+  vd.init(p.v_stride, w, lane);
+  f32x16 sa, sb;
+  bf16x8 pa[2], pb[2];
+  constexpr int PK = DmaPlan<D, NW, false>::PER;       // DMA pieces per tile and wave
+  constexpr int AHEAD = NB - 1;                         // K tile i + AHEAD and V tile i + AHEAD - 1 are requested in iteration i
+  if (ntiles > 0) {
+    // prologue: K tiles 0..AHEAD, V tiles 0..AHEAD-1 by DMA; QK(0); step 0
+    kd.issue(kg, p.k_stride, 0, lk_, ks_a(0), w);
+    vd.issue(vg, p.v_stride, 0, lk_, vs_a(0), w);
+    if (ntiles > 1) kd.issue(kg, p.k_stride, KT, lk_, ks_a(1), w);
+    if (NB == 3) {
+      if (ntiles > 1) vd.issue(vg, p.v_stride, KT, lk_, vs_a(1), w);
+      if (ntiles > 2) kd.issue(kg, p.k_stride, 2 * KT, lk_, ks_a(2), w);
+    }
+    if (NB == 3 && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PK) : "memory");   // K0, V0, K1 have landed; V1, K2 stay in flight
+    else dma_wait();
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) asm volatile("" :: "v"(qf.v[s]));   // Q has landed too: no vmcnt wait for it inside the loop
+    if (wave_live) {
+      qk_unit(ks[0], 0, sa);
+      step(sa, pa, sb, pb, 0, false, nunits > 1, vs[0], 0, ks[0], 32);
+    }
+    __syncthreads();                                    // every wave is done with K tile 0 before iteration 1 refills its buffer
+    // iteration i: steps 2i-1 and 2i; reads K tile i and V tile i-1; its DMA (riding in the MFMA gaps of its first
+    // step) requests K tile i+AHEAD into the buffer K tile i-1 left and V tile i+AHEAD-1 into the buffer V tile i-2
+    // left, both last read before the previous barrier: ONE barrier per 64 keys.  With three buffers the wait ahead
+    // of that barrier covers only the PREVIOUS iteration's pieces: a request has two iterations to land.
+    int i = 1;
+    for (; 2 * i + 1 < nunits; ++i) {                   // both steps have a block ahead and a block behind
+      STAMP(t0_);
+      const int tk = i + AHEAD, tv = i + AHEAD - 1;     // tiles requested in this iteration
+      const bool more_k = tk < ntiles, more_v = tv < ntiles;
+      const unsigned char* kc = ks[i % NB];
+      const unsigned char* vp = vs[(i - 1) % NB];
+      auto dma_hook = [&](int g) {                      // pieces spread over gaps 1 .. NM-1, K first
+        constexpr int C = (2 * PK + NM - 2) / (NM - 1);
+        if (g < 1) return;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          const int q = (g - 1) * C + c;
+          if (q < PK) { if (more_k) kd.piece(q, kg, p.k_stride, (int64_t)tk * KT, lk_, ks_a(tk), w); }
+          else if (q < 2 * PK) { if (more_v) vd.piece(q - PK, vg, p.v_stride, (int64_t)tv * KT, lk_, vs_a(tv), w); }
+        }
+      };
+      STAMP(t1_);
+      if (wave_live) {
+        step_full(sb, pb, sa, pa, 2 * i - 1, vp, 0, kc, 0, dma_hook);
+        step_full(sa, pa, sb, pb, 2 * i, vp, 32, kc, 32, [](int) {});
+      } else {
+#pragma unroll
+        for (int g = 0; g < NM; ++g) dma_hook(g);
+      }
+      STAMP(t2_);
+      if (NB == 3 && more_k) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PK) : "memory");   // more_k implies more_v: exactly 2 PK pieces of this iteration may stay in flight
+      else dma_wait();
+      STAMP(t3_);
+      __syncthreads();
+      STAMP(t4_);
+#ifdef GMLM_ATTN_STAMP
+      t_load += t1_ - t0_; t_steps += t2_ - t1_; t_stage += t3_ - t2_; t_bar += t4_ - t3_;
+#endif
+    }
+    for (; 2 * i - 1 < nunits; ++i) {                   // tail: the last one or two blocks
+      const int tv = i + AHEAD - 1;
+      if (tv < ntiles && NB == 2) vd.issue(vg, p.v_stride, (int64_t)tv * KT, lk_, vs_a(tv), w);   // (with three buffers the last V tile is already on its way)
+      const unsigned char* kc = ks[i % NB];
+      const unsigned char* vp = vs[(i - 1) % NB];
+      if (wave_live) {
+        step(sb, pb, sa, pa, 2 * i - 1, true, 2 * i < nunits, vp, 0, kc, 0);
+        if (2 * i < nunits) step(sa, pa, sb, pb, 2 * i, true, false, vp, 32, kc, 32);
+        else pv_unit(vp, 32, pb);                                       // nunits even: last block retired here
+      }
+      dma_wait();
+      __syncthreads();
+    }
+    if ((nunits & 1) && wave_live) pv_unit(vs[(ntiles - 1) % NB], 0, pa);   // nunits odd: last block = first half of the last V tile
+  }
+#ifdef GMLM_ATTN_STAMP
+  if (lane == 0 && p.delta) {     // diagnostic build: p.delta = uint64 [waves][6]
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.delta) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + w) * 6;
+    dbg[0] = t_load; dbg[1] = t_steps; dbg[2] = t_stage; dbg[3] = t_bar; dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; dbg[5] = (uint64_t)nunits;
+  }
+#endif
+  if (q_ok) {
+    l = xhalf_sum(l);
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
+    if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
+  }
+}
+
+template <int D, int NW, int NB>
+static int launch_pipe(dim3 grid, hipStream_t st, const AttnParams& p) {
+  constexpr int kLds = 2 * NB * Img<D>::TILE;
+  static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs the attribute once per instantiation
+  if (!attr_set) {
+    GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<D, NW, true, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<D, NW, false, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
+    attr_set = true;
+  }
+  if (p.drop_thresh) attn_fwd_pipe_kernel<D, NW, true, NB><<<grid, NW * 64, kLds, st>>>(p);
+  else attn_fwd_pipe_kernel<D, NW, false, NB><<<grid, NW * 64, kLds, st>>>(p);
+  return GMLM_OK;
+}
+
+// bf16 forward entry used by gmlm_attention_fwd (attn_kernels.hip); nw = waves per workgroup (4 or 8).  Only the
+// configurations that are dispatched are instantiated (d = 96, two LDS buffers per operand); the kernel template also
+// covers d = 64 and a 3-deep ring, both measured and not adopted.
+int attn_fwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t bh, hipStream_t st) {
+  dim3 grid((unsigned)cdiv(rows_q, nw * 32), (unsigned)bh);
+  if (d == 96 && nw == 8) return launch_pipe<96, 8, 2>(grid, st, p);
+  if (d == 96 && nw == 4) return launch_pipe<96, 4, 2>(grid, st, p);
+  set_error("attention_fwd: no pipelined kernel for d = %d with %d waves", d, nw);
+  return GMLM_EINVAL;
+}
+
+}  // namespace gmlm

@@ -24,10 +24,11 @@ __global__ void i32_to_f32_kernel(const int32_t* __restrict__ a, int64_t n, floa
     o[i] = (float)a[i];
 }
 
-__global__ void edge_bucket_kernel(const int64_t* __restrict__ src, const int32_t* __restrict__ deg, int64_t e,
+__global__ void edge_bucket_kernel(const int64_t* __restrict__ src, const int32_t* __restrict__ deg, int64_t e, int64_t n,
                                    int64_t* __restrict__ edge_type) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < e; i += (int64_t)gridDim.x * blockDim.x) {
-    const int32_t d = deg[src[i]];
+    const int64_t s = src[i];
+    const int32_t d = (s >= 0 && s < n) ? deg[s] : 0;     // ids outside the graph are rejected later (segment sort); never read out of bounds
     edge_type[i] = d <= 2 ? 0 : (d <= 5 ? 1 : (d <= 10 ? 2 : 3));
   }
 }
@@ -117,11 +118,11 @@ extern "C" int gmlm_degree_f32(const int64_t* index, int64_t e, int64_t n, float
   return GMLM_OK;
 }
 
-extern "C" int gmlm_edge_bucket(const int64_t* src, const int32_t* deg, int64_t e, int64_t* edge_type,
+extern "C" int gmlm_edge_bucket(const int64_t* src, const int32_t* deg, int64_t e, int64_t n, int64_t* edge_type,
                                 gmlm_stream_t stream) {
-  GMLM_REQUIRE(e >= 0 && (e == 0 || (src && deg && edge_type)), "edge_bucket: bad arguments");
+  GMLM_REQUIRE(e >= 0 && n >= 0 && (e == 0 || (src && deg && edge_type)), "edge_bucket: bad arguments");
   if (e == 0) return GMLM_OK;
-  edge_bucket_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(src, deg, e, edge_type);
+  edge_bucket_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(src, deg, e, n, edge_type);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }

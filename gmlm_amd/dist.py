@@ -7,7 +7,7 @@ parameters are replicated.  Exchange steps (nothing else communicates):
   a2  edge types       global out-degree of each source: computed from the full edge list at
                        partition time (static graph), integer, bit-exact
   a3  RGCN aggregation halo exchange before each layer: all-to-all-v of the owned rows that remote
-                       targets reference (deduplicated), reverse all-to-all-v + index_add backward
+                       targets reference (deduplicated), reverse all-to-all-v + per-peer (collision-free, fixed-order) row adds backward
   a4  GraphNorm        all-reduce(sum) of [2, F] fp32 column statistics (forward: twice, exact
                        two-pass; backward: once)
   a9  CrossAttention   all-gather of the fused K|V projection rows (local Q x all keys); backward =
@@ -132,7 +132,14 @@ class _HaloExchange(torch.autograd.Function):
         back = g_halo.new_empty((part.send_idx.numel(),) + tuple(g.shape[1:]))
         dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group)
         gx = g[:n].clone()
-        gx.index_add_(0, part.send_idx, back.to(g.device))
+        back = back.to(g.device)
+        # deterministic: a row goes to a given peer at most once, so each peer's slice has unique targets (its adds
+        # cannot collide) and the slices are applied in fixed peer order: no run-to-run reordering of the sum
+        off = 0
+        for cnt in plan.send_counts:
+            if cnt:
+                gx.index_add_(0, part.send_idx[off:off + cnt], back[off:off + cnt])
+            off += cnt
         return gx, None
 
 
@@ -202,14 +209,28 @@ class PartitionContext:
     def with_halo(self, x: torch.Tensor) -> torch.Tensor:
         return _HaloExchange.apply(x, self)
 
-    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
-        if t.is_cuda and _is_gloo(self.group):
-            c = t.cpu()
-            dist.all_reduce(c, group=self.group)
-            t.copy_(c)
+    def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
+        """In-place all-reduce of ``t`` wherever it lives: gloo has no device collectives (device tensors are staged
+        through the host: tests / 1-GPU rehearsals), RCCL has no host collectives (small host tensors are staged
+        through the device)."""
+        gloo = _is_gloo(self.group)
+        if t.is_cuda == (not gloo):
+            dist.all_reduce(t, op=op, group=self.group)
         else:
-            dist.all_reduce(t, group=self.group)
+            c = t.cpu() if gloo else t.to(self.device)
+            dist.all_reduce(c, op=op, group=self.group)
+            t.copy_(c)
         return t
+
+    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
+        return self._all_reduce(t, dist.ReduceOp.SUM)
+
+    def all_reduce_min(self, t: torch.Tensor) -> torch.Tensor:
+        """MIN over ranks (collective yes / no decisions)."""
+        return self._all_reduce(t, dist.ReduceOp.MIN)
+
+    def all_reduce_max(self, t: torch.Tensor) -> torch.Tensor:
+        return self._all_reduce(t, dist.ReduceOp.MAX)
 
     def all_gather_rows(self, x: torch.Tensor) -> torch.Tensor:
         return _AllGatherRows.apply(x, self)
@@ -219,7 +240,15 @@ class PartitionContext:
 
     def all_reduce_grads(self, module: torch.nn.Module, bucket_bytes: int = 256 << 20) -> None:
         """Sum replicated parameter gradients over ranks in a few large flat buckets (xGMI is per-link
-        bound: few big messages).  Parameters without a local gradient contribute zeros."""
+        bound: few big messages).  Which parameters take part is decided collectively: a parameter that has a
+        gradient on SOME rank is summed (ranks without one contribute zeros); a parameter without a gradient on
+        ANY rank (the dead ``residual_proj3`` branch, the unused BERT pooler) keeps ``grad = None`` exactly like
+        the single-GPU / reference run, so AdamW neither decays it nor creates state for it."""
+        params = [p for p in module.parameters()
+                  if p.requires_grad and not getattr(p, "_gmlm_grad_reduced", False)]   # else: frozen, or summed inside backward (RGCN bases)
+        has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params])
+        if has.numel():
+            self.all_reduce_max(has)
         bucket, size = [], 0
 
         def flush():
@@ -235,9 +264,9 @@ class PartitionContext:
                 off += n
             bucket, size = [], 0
 
-        for p in module.parameters():
-            if not p.requires_grad or getattr(p, "_gmlm_grad_reduced", False):
-                continue                      # frozen, or already summed over ranks inside backward (RGCN bases)
+        for p, h in zip(params, has.tolist()):
+            if h < 0.5:
+                continue                      # no rank has a gradient for it
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
             bucket.append(p.grad)

@@ -107,7 +107,7 @@ def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
         else:
             edge_type = torch.empty(e, dtype=torch.long, device=dev)
             deg = src_degree_for_types.to(torch.int32).contiguous()
-            check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, _ptr(edge_type), st), "gmlm_edge_bucket")
+            check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, deg.numel(), _ptr(edge_type), st), "gmlm_edge_bucket")
     else:
         edge_type = edge_type.to(device=dev, dtype=torch.long).contiguous()
     cnt = torch.empty(num_relations, dtype=torch.int32, device=dev)
@@ -144,23 +144,30 @@ def build_rel_csr(edge_index: torch.Tensor, num_nodes: int, num_relations: int,
 
 
 class GraphCache:
-    """Small LRU keyed by the identity of ``edge_index`` / ``edge_type`` storage (static graph)."""
+    """Small LRU keyed by the identity of the CALLER's ``edge_index`` / ``edge_type`` tensors (static graph): storage
+    pointer, shape, dtype, device and version counter, taken before any dtype cast (an int32 edge_index would
+    otherwise be re-cast to a fresh int64 tensor — a new pointer — and miss on every step)."""
 
     def __init__(self, capacity: int = 4):
         self.capacity = capacity
         self._items = {}
 
     @staticmethod
-    def _key(edge_index, edge_type, num_nodes, num_relations):
-        k = (edge_index.data_ptr(), tuple(edge_index.shape), edge_index._version, num_nodes, num_relations)
+    def _ident(t):
+        return (t.data_ptr(), tuple(t.shape), t.dtype, str(t.device), t._version)
+
+    @classmethod
+    def _key(cls, edge_index, edge_type, num_nodes, num_relations):
+        k = cls._ident(edge_index) + (num_nodes, num_relations)
         if edge_type is not None:
-            k += (edge_type.data_ptr(), edge_type._version)
+            k += cls._ident(edge_type)
         return k
 
     def get(self, edge_index, num_nodes, num_relations, edge_type=None) -> RelCSR:
         key = self._key(edge_index, edge_type, num_nodes, num_relations)
-        hit = self._items.get(key)
+        hit = self._items.pop(key, None)
         if hit is not None:
+            self._items[key] = hit                        # most recently used last
             return hit[0]
         csr = build_rel_csr(edge_index, num_nodes, num_relations, edge_type)
         if len(self._items) >= self.capacity:

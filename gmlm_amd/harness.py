@@ -105,22 +105,44 @@ def nt_xent_loss(z1, z2, temperature=0.5, batch_size=8):
     return loss
 
 
+def _all_flags(model, *flags: bool):
+    """AND of per-rank boolean decisions over the partition group (identity on a single GPU): every rank must take
+    the same branch, otherwise the ranks that go on sit in the halo / GraphNorm / K|V collectives forever."""
+    if model.dist is None:
+        return flags
+    t = model.dist.all_reduce_min(torch.tensor([1.0 if f else 0.0 for f in flags]))
+    return tuple(bool(v > 0.5) for v in t.tolist())
+
+
 def pretrain_step(model, optimizer, x, edge_index, mask1, mask2, *, beta=0.7, temperature=0.5, autocast=True):
     """One iteration of ``pretrain_contrastive_gnn`` (main.py:438-456): two soft-masked views ->
-    ``get_graph_embeddings`` twice (the graph preprocessing is cached, not redone per view) -> NT-Xent."""
+    ``get_graph_embeddings`` twice (the graph preprocessing is cached, not redone per view) -> NT-Xent.
+
+    Node partition (``model.dist``): the reference chunks the N embeddings into groups of 8 consecutive rows
+    (main.py:112-131); the embeddings of both views are therefore all-gathered (rows in global order) and every
+    rank evaluates the SAME global loss, so the gradient that flows back through the reduce-scatter is the
+    single-GPU gradient and the all-reduced parameter gradients need no rescaling."""
     model.train()
     optimizer.zero_grad(set_to_none=True)
     with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
         g1 = model.get_graph_embeddings(model.soft_mask_input(x, mask1, beta), edge_index, edge_type=None)
         g2 = model.get_graph_embeddings(model.soft_mask_input(x, mask2, beta), edge_index, edge_type=None)
+        if model.dist is not None:
+            g1 = model.dist.all_gather_rows(g1.unsqueeze(0)).squeeze(0)
+            g2 = model.dist.all_gather_rows(g2.unsqueeze(0)).squeeze(0)
         loss = nt_xent_loss(g1, g2, temperature=temperature, batch_size=8)
-    if not bool(torch.isfinite(loss)):
+        if model.dist is not None:
+            loss = loss / model.dist.plan.world          # every rank holds the same loss; the gradient all-reduce SUMS them
+    (finite,) = _all_flags(model, bool(torch.isfinite(loss)))
+    if not finite:
         return float(loss)
     loss.backward()
+    scale = 1.0
     if model.dist is not None:
         model.dist.all_reduce_grads(model)
+        scale = float(model.dist.plan.world)
     optimizer.step()
-    return float(loss.detach())
+    return float(loss.detach()) * scale
 
 
 @dataclass
@@ -132,29 +154,58 @@ class StepResult:
 
 def train_step(model, optimizer, scheduler, x, edge_index, texts, y, active_mask, *, beta=0.7, plm_batch_size=32,
                grad_clip_norm=1.0, autocast: bool = True, label_smoothing=0.2) -> StepResult:
-    """One iteration of the epoch loop main.py:528-563 (full-batch: one forward + backward per epoch)."""
+    """One iteration of the epoch loop main.py:528-563 (full-batch: one forward + backward per epoch).
+
+    Node partition (``model.dist``; x / texts / y / active_mask are this rank's rows): the loss is the GLOBAL mean
+    over all active nodes (local sum / all-reduced count), so the summed gradients equal the single-GPU ones and
+    ``clip_grad_norm_`` sees the same norm; the skip decisions (no active node anywhere, non-finite loss anywhere)
+    are taken collectively; a rank without a local active node still runs forward and backward with a zero loss
+    term, because its peers need it in the halo / GraphNorm / K|V exchanges."""
     model.train()
     optimizer.zero_grad(set_to_none=True)
-    if not bool(active_mask.any()):
-        return StepResult(float('nan'), 0.0, True)
+    dist_ctx = model.dist
+    n_local = int(active_mask.sum()) if dist_ctx is not None else None
+    if dist_ctx is None:
+        if not bool(active_mask.any()):
+            return StepResult(float('nan'), 0.0, True)
+        n_active = None
+    else:
+        cnt = torch.tensor([float(n_local)])
+        dist_ctx.all_reduce_sum(cnt)
+        n_active = int(cnt.item())
+        if n_active == 0:                                  # the same decision on every rank
+            return StepResult(float('nan'), 0.0, True)
     with torch.amp.autocast('cuda', dtype=torch.bfloat16, enabled=autocast):
         xm = model.soft_mask_input(x, active_mask, beta)
         logits = model(xm, edge_index, texts, active_mask, edge_type=None, plm_batch_size=plm_batch_size)
         idx = model.active_index                # ascending ids of the active nodes, built by the forward (same rows as
-        la, ya = logits.index_select(0, idx), y.index_select(0, idx)          # logits[active_mask], without its sync)
-        loss = F.cross_entropy(la, ya, label_smoothing=label_smoothing)
+        if idx is None:                         # logits[active_mask], without its sync); None = no local active node
+            idx = torch.zeros(0, dtype=torch.long, device=logits.device)
+        la, ya = logits.index_select(0, idx), y.index_select(0, idx)
+        if dist_ctx is None:
+            loss = F.cross_entropy(la, ya, label_smoothing=label_smoothing)
+        else:
+            loss = F.cross_entropy(la, ya, label_smoothing=label_smoothing, reduction='sum') / n_active if idx.numel() \
+                else logits.sum() * 0.0
     with torch.no_grad():
-        acc = float((la.argmax(1) == ya).float().mean())
-    if not bool(torch.isfinite(loss)):
-        return StepResult(float(loss), acc, True)
+        hits = (la.argmax(1) == ya).float().sum() if idx.numel() else torch.zeros((), device=logits.device)
+        if dist_ctx is None:
+            acc, loss_value = float(hits / max(idx.numel(), 1)), loss.detach()
+        else:
+            agg = torch.stack([hits.cpu(), loss.detach().float().cpu()])
+            dist_ctx.all_reduce_sum(agg)
+            acc, loss_value = float(agg[0]) / n_active, agg[1]
+    (finite,) = _all_flags(model, bool(torch.isfinite(loss)))
+    if not finite:
+        return StepResult(float(loss_value), acc, True)
     loss.backward()
-    if model.dist is not None:
-        model.dist.all_reduce_grads(model)
+    if dist_ctx is not None:
+        dist_ctx.all_reduce_grads(model)
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=grad_clip_norm)
     optimizer.step()
     if scheduler is not None:
         scheduler.step()
-    return StepResult(float(loss.detach()), acc)
+    return StepResult(float(loss_value), acc)
 
 
 @torch.no_grad()

@@ -127,8 +127,7 @@ class GraphTextLM(nn.Module):
         return ops.bias_gelu(z, None, drop.p, self.training)
 
     def get_graph_embeddings(self, x_feat, edge_index, edge_type=None):
-        edge_index = edge_index.to(torch.long)
-        csr = self.graph(edge_index, x_feat.size(0), edge_type)
+        csr = self.graph(edge_index, x_feat.size(0), edge_type)      # cache keyed by the caller's tensor; the int64 cast (main.py:323) happens inside the build
         cd = self._cd()
         align = 8 if cd == torch.bfloat16 else 4
         f_in = self.rgcn1.in_channels
@@ -157,10 +156,11 @@ class GraphTextLM(nn.Module):
     # ------------------------------------------------------------------------------------------
     def tokenize(self, all_node_texts) -> TokenizedTexts:
         """Tokenise every node text once on the host (same tokenizer call as main.py:342-345) and keep
-        the ids on the device; keyed by the identity of the text list."""
+        the ids on the device.  The cache is keyed by the identity of the text list AND its content (length +
+        hash of the strings: ~1 ms per 10k texts), so a list mutated in place is re-tokenised."""
         if isinstance(all_node_texts, TokenizedTexts):
             return all_node_texts
-        key = id(all_node_texts)
+        key = (id(all_node_texts), len(all_node_texts), hash(tuple(all_node_texts)))
         hit = self._tokens.get(key)
         if hit is not None and hit[1] is all_node_texts:
             return hit[0]
@@ -170,6 +170,11 @@ class GraphTextLM(nn.Module):
         tt = TokenizedTexts.from_mask(enc["input_ids"].to(dev), enc["attention_mask"].to(dev))
         self._tokens = {key: (tt, all_node_texts)}
         return tt
+
+    def clear_caches(self):
+        """Drop the cached graph preprocessing (CSR) and tokenisation."""
+        self._graphs.clear()
+        self._tokens = {}
 
     def start_mask_copy(self, node_mask: torch.Tensor):
         """Begin the device -> pinned-host copy of the active-node mask and mark its completion with an event.
@@ -246,7 +251,6 @@ class GraphTextLM(nn.Module):
 
     def forward(self, gnn_input_features, edge_index, all_node_texts, text_processing_node_mask, edge_type=None,
                 plm_batch_size=8):
-        edge_index = edge_index.to(torch.long)
         mask_copy = self.start_mask_copy(text_processing_node_mask)                              # async; consumed below
         # the per-step compute-dtype copy of the PLM weights does not depend on the mask: its host-side set-up
         # (0.6 ms) runs here, under device work that is still queued, not between the GNN and the PLM launches

@@ -140,7 +140,7 @@ def edge_types_from_degree(edge_index: torch.Tensor, num_nodes: int) -> torch.Te
     deg = torch.empty(num_nodes, dtype=torch.int32, device=src.device)
     check(lib().gmlm_degree_i32(_ptr(src), e, num_nodes, _ptr(deg), _stream()), "gmlm_degree_i32")
     et = torch.empty(e, dtype=torch.long, device=src.device)
-    check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, _ptr(et), _stream()), "gmlm_edge_bucket")
+    check(lib().gmlm_edge_bucket(_ptr(src), _ptr(deg), e, num_nodes, _ptr(et), _stream()), "gmlm_edge_bucket")
     return et
 
 

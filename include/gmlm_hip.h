@@ -56,8 +56,10 @@ int gmlm_device_check(int* cu_count, int* wave_size, char* arch, int arch_len);
 int gmlm_degree_i32(const int64_t* index, int64_t e, int64_t n, int32_t* deg, gmlm_stream_t stream);
 /* PyG `degree` drop-in: float32 counts. */
 int gmlm_degree_f32(const int64_t* index, int64_t e, int64_t n, float* deg, gmlm_stream_t stream);
-/* edge_type[e] = 0 if deg[src[e]] <= 2, 1 if <= 5, 2 if <= 10, else 3   (main.py:260-267) */
-int gmlm_edge_bucket(const int64_t* src, const int32_t* deg, int64_t e, int64_t* edge_type, gmlm_stream_t stream);
+/* edge_type[e] = 0 if deg[src[e]] <= 2, 1 if <= 5, 2 if <= 10, else 3   (main.py:260-267).  deg has n entries; a
+ * source id outside [0, n) is typed 0 here (no out-of-bounds read) and rejected by gmlm_segment_sort's checks. */
+int gmlm_edge_bucket(const int64_t* src, const int32_t* deg, int64_t e, int64_t n, int64_t* edge_type,
+                     gmlm_stream_t stream);
 /* rel_count[r] = #{e : edge_type[e] == r}, r < num_relations (zeroed by the call). */
 int gmlm_relation_histogram(const int64_t* edge_type, int64_t e, int num_relations, int32_t* rel_count,
                             gmlm_stream_t stream);
