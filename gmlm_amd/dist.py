@@ -10,12 +10,19 @@ parameters are replicated.  Exchange steps (nothing else communicates):
                        targets reference (deduplicated), reverse all-to-all-v + per-peer (collision-free, fixed-order) row adds backward
   a4  GraphNorm        all-reduce(sum) of [2, F] fp32 column statistics (forward: twice, exact
                        two-pass; backward: once)
-  a9  CrossAttention   all-gather of the fused K|V projection rows (local Q x all keys); backward =
-                       reduce-scatter of dK|dV.  (Ring exchange for graphs whose K/V do not fit is the
-                       next step; S3/S4-size K/V are a few MB.)
-  grads               one bucketed all-reduce(sum) of the replicated parameter gradients per step; the RGCN
-                       basis weights (70 % of the parameters) are reduced as the R_a composed relation
-                       weights instead of the 30 bases (30/R_a times fewer bytes)
+  a9  CrossAttention   small graphs: all-gather of the fused K|V projection rows (local Q x all keys), backward =
+                       reduce-scatter of dK|dV.  Large graphs (``use_ring``): ring exchange — the K|V blocks
+                       travel rank to rank (point-to-point send/recv posted BEFORE the block's attention is
+                       computed, so the transfer hides under it), each step yields (O_j, lse_j) and the running
+                       (O, lse) is merged with carried online-softmax state; K|V is never gathered.  Backward is
+                       a second ring: the blocks travel again, each rank adds its dK|dV contribution to the
+                       accumulator that travels with the block.
+  grads               bucketed all-reduce(sum) of the replicated parameter gradients.  ``GradBuckets`` keeps the
+                       gradients as views into a few flat fp32 buffers (no torch.cat / copy-back) and launches a
+                       bucket's all-reduce from a post-accumulate hook as soon as its last gradient is final,
+                       i.e. under the rest of backward.  The RGCN basis weights (70 % of the parameters) are
+                       reduced as the R_a composed relation weights instead of the 30 bases (30/R_a times fewer
+                       bytes)
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): the halo all-to-all-v drives all links at once,
 and gradients go out as a few large flat buckets rather than per-tensor rings.
@@ -114,14 +121,31 @@ def plan_partition(edge_index: torch.Tensor, n_total: int, world: int, rank: int
 
 
 class _HaloExchange(torch.autograd.Function):
+    """x [n_local, ...] -> [n_local + n_halo, ...]: owned rows, then the remote rows this rank's edges reference.
+
+    The receive lands directly in the tail of the output buffer (no torch.cat pass).  With a device-capable backend
+    (RCCL) the all-to-all-v is started asynchronously and the wait is deferred to ``PartitionContext.wait_halo()``:
+    the caller runs the work that does not need the halo rows (the root GEMM x W_root of RGCNConv) in between, so
+    the exchange of layer k hides under it."""
+
     @staticmethod
-    def forward(ctx, x, part):
+    def forward(ctx, x, part, defer):
         plan, group = part.plan, part.group
-        send = _staged(x.index_select(0, part.send_idx).contiguous(), group)
-        recv = send.new_empty((plan.n_halo,) + tuple(x.shape[1:]))
-        dist.all_to_all_single(recv, send, plan.recv_counts, plan.send_counts, group=group)
+        n = plan.n_local
         ctx.part = part
-        return torch.cat([x, recv.to(x.device)], 0)
+        send = x.index_select(0, part.send_idx).contiguous()
+        out = x.new_empty((n + plan.n_halo,) + tuple(x.shape[1:]))
+        out[:n] = x
+        if x.is_cuda and _is_gloo(group):                     # rehearsal path: stage through the host, synchronous
+            recv = send.cpu().new_empty((plan.n_halo,) + tuple(x.shape[1:]))
+            dist.all_to_all_single(recv, send.cpu(), plan.recv_counts, plan.send_counts, group=group)
+            out[n:] = recv.to(x.device)
+            return out
+        work = dist.all_to_all_single(out[n:], send, plan.recv_counts, plan.send_counts, group=group, async_op=True)
+        part._halo_pending.append((work, send))               # keep the send buffer alive until the wait
+        if not defer:
+            part.wait_halo()
+        return out
 
     @staticmethod
     def backward(ctx, g):
@@ -140,7 +164,7 @@ class _HaloExchange(torch.autograd.Function):
             if cnt:
                 gx.index_add_(0, part.send_idx[off:off + cnt], back[off:off + cnt])
             off += cnt
-        return gx, None
+        return gx, None, None
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -185,6 +209,244 @@ class _AllGatherRows(torch.autograd.Function):
         return out.to(g.device).transpose(0, 1).contiguous(), None
 
 
+def _merge_partial(o_acc, lse_acc, o_j, lse_j):
+    """Carried online-softmax state: (O, lse) of the keys seen so far merged with a new block's (O_j, lse_j).
+    o: [b, n, h, d] fp32 (normalised per block), lse: [b, h, n] fp32 (natural log of the block's softmax sum)."""
+    lse_new = torch.logaddexp(lse_acc, lse_j)
+    w_acc = torch.exp(lse_acc - lse_new).transpose(1, 2).unsqueeze(-1)          # [b, n, h, 1]; exp(-inf) = 0 for the empty start
+    w_j = torch.exp(lse_j - lse_new).transpose(1, 2).unsqueeze(-1)
+    return o_acc * w_acc + o_j * w_j, lse_new
+
+
+class _RingAttention(torch.autograd.Function):
+    """softmax(Q_local K_all^T * scale) V_all without ever holding K_all / V_all: W steps, each on one rank's K|V block.
+
+    ``block`` supplies the per-block arithmetic: ``block.fwd(q, k, v, kv_len, seed) -> (o [b,n,h*d], lse [b,h,n])`` and
+    ``block.bwd(q, k, v, out, dout, lse, kv_len, seed) -> (dq, dk, dv)`` given the GLOBAL out / lse (the HIP kernels on
+    the GPU: gmlm_amd.ops.AttentionBlock; a torch restatement in the CPU tests).  Blocks are padded to the largest
+    share and masked by their true row count, so every message has the same size.  Attention-probability dropout
+    draws a per-block seed (seed + owner rank): the masks differ from the all-gather path's, the distribution does
+    not."""
+
+    @staticmethod
+    def forward(ctx, q, kv, part, h, block, seed):
+        world, rank, group = part.plan.world, part.plan.rank, part.group
+        sizes = [r[1] - r[0] for r in part.ranges]
+        mx = max(sizes)
+        b, n, c = q.shape
+        cur = kv.new_zeros(b, mx, 2 * c)
+        cur[:, :kv.shape[1]] = kv
+        acc_t = torch.promote_types(q.dtype, torch.float32)       # fp32 state for bf16 / fp32 operands
+        o_acc = torch.zeros(b, n, h, c // h, dtype=acc_t, device=q.device)
+        lse_acc = torch.full((b, h, n), float("-inf"), dtype=acc_t, device=q.device)
+        nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+        for s in range(world):
+            owner = (rank - s) % world
+            pend, nxt = None, None
+            if s + 1 < world:                                   # the next block is on its way while this one is computed
+                nxt = torch.empty_like(cur)
+                pend = _exchange(cur, nxt, nxt_rank, prv_rank, group)
+            kv_len = torch.full((b,), sizes[owner], dtype=torch.int32, device=q.device)
+            o_j, lse_j = block.fwd(q, cur[..., :c], cur[..., c:], kv_len, seed + owner)
+            o_acc, lse_acc = _merge_partial(o_acc, lse_acc, o_j.to(acc_t).view(b, n, h, c // h), lse_j.to(acc_t))
+            if pend is not None:
+                pend.wait()
+                cur = nxt
+        out = o_acc.view(b, n, c).to(q.dtype)
+        ctx.save_for_backward(q, kv, out, lse_acc)
+        ctx.cfg = (part, h, block, seed, sizes, mx)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        part, h, block, seed, sizes, mx = ctx.cfg
+        world, rank, group = part.plan.world, part.plan.rank, part.group
+        b, n, c = q.shape
+        dout = dout.contiguous().to(q.dtype)
+        cur = kv.new_zeros(b, mx, 2 * c)
+        cur[:, :kv.shape[1]] = kv
+        acc_t = torch.promote_types(q.dtype, torch.float32)
+        dcur = torch.zeros(b, mx, 2 * c, dtype=acc_t, device=q.device)            # gradient accumulator that travels with the block
+        dq = torch.zeros(b, n, c, dtype=acc_t, device=q.device)
+        nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+        for s in range(world):
+            owner = (rank - s) % world
+            pend, nxt = None, None
+            if s + 1 < world:
+                nxt = torch.empty_like(cur)
+                pend = _exchange(cur, nxt, nxt_rank, prv_rank, group)
+            kv_len = torch.full((b,), sizes[owner], dtype=torch.int32, device=q.device)
+            dq_j, dk_j, dv_j = block.bwd(q, cur[..., :c], cur[..., c:], out, dout, lse.to(torch.promote_types(lse.dtype, torch.float32)), kv_len, seed + owner)
+            dq += dq_j.to(acc_t)
+            dcur[..., :c] += dk_j.to(acc_t)
+            dcur[..., c:] += dv_j.to(acc_t)
+            if pend is not None:
+                pend.wait()
+            # the accumulator follows its block (after the last step it makes the closing hop home)
+            dnxt = torch.empty_like(dcur)
+            _exchange(dcur, dnxt, nxt_rank, prv_rank, group).wait()
+            dcur = dnxt
+            if nxt is not None:
+                cur = nxt
+        return dq.to(q.dtype), dcur[:, :kv.shape[1]].to(kv.dtype), None, None, None, None
+
+
+def _exchange(send_t, recv_t, dst, src, group):
+    """Post send(send_t -> dst) and recv(recv_t <- src) together.  Returns an object whose ``wait()`` completes both
+    (gloo cannot move device memory: rehearsals stage through the host and copy back inside ``wait``)."""
+    staged = send_t.is_cuda and _is_gloo(group)
+    s_buf = send_t.cpu() if staged else send_t
+    r_buf = torch.empty(recv_t.shape, dtype=recv_t.dtype) if staged else recv_t
+    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, s_buf, dst, group), dist.P2POp(dist.irecv, r_buf, src, group)])
+
+    class _Pending:
+        def wait(self):
+            for r in reqs:
+                r.wait()
+            if staged:
+                recv_t.copy_(r_buf)
+            del s_buf_keep[:]
+    s_buf_keep = [s_buf]                                      # the send buffer must outlive the transfer
+    return _Pending()
+
+
+class GradBuckets:
+    """Gradient all-reduce that overlaps with backward and never copies gradients.
+
+    The gradients of the replicated parameters live as VIEWS inside a few flat fp32 buffers (``prepare()`` installs
+    the views and zeroes the buffers with one memset each: it replaces ``zero_grad``).  A post-accumulate hook counts
+    a bucket's gradients down; when the last one is final the bucket's all-reduce starts, asynchronously, while
+    backward continues with the earlier layers (buckets are filled in reverse parameter order).  Buckets are always
+    LAUNCHED in bucket order, so every rank issues the same collective sequence even when a rank's gradients become
+    final at different times or not at all (a rank without active text nodes never sees a PLM gradient: it launches
+    those buckets in ``finish()``).
+
+    Which parameters take part is a collective decision made on the first step (``finish()`` votes with MAX on "got a
+    gradient"): a parameter without a gradient on ANY rank (dead ``residual_proj3``, BERT pooler) keeps ``grad =
+    None`` like the single-GPU run, and is not waited for afterwards.  If a parameter outside that set ever receives
+    a gradient, the set is re-learned (that step reduces it separately)."""
+
+    def __init__(self, part, module, bucket_bytes: int = 256 << 20):
+        from .nn import RGCNConv
+        self.part = part
+        skip = set()
+        for m in module.modules():                              # reduced inside backward as composed relation weights
+            if isinstance(m, RGCNConv):
+                skip.update((id(m.weight), id(m.comp)))
+        self.params = [p for p in module.parameters() if p.requires_grad and id(p) not in skip][::-1]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.bucket_bytes = bucket_bytes
+        self.expected = None                                    # bool list once learned
+        self.buckets = []
+        self._works = []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._active = False
+
+    # -- layout --------------------------------------------------------------------------------------------------
+    def _build(self):
+        keep = [i for i in range(len(self.params)) if self.expected is None or self.expected[i]]
+        self.buckets, cur, size = [], [], 0
+        for i in keep:
+            cur.append(i)
+            size += self.params[i].numel() * 4
+            if size >= self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flats = []
+        self.bucket_of = {}
+        for b, idxs in enumerate(self.buckets):
+            dev = self.params[idxs[0]].device
+            self.flats.append(torch.zeros(sum(self.params[i].numel() for i in idxs), dtype=torch.float32, device=dev))
+            for i in idxs:
+                self.bucket_of[i] = b
+
+    def prepare(self):
+        """Before backward (instead of zero_grad): zero the flat buffers, point every expected parameter's .grad at
+        its slice, drop the others' gradients."""
+        if not self.buckets or self._layout_for is not self.expected:
+            self._build()
+            self._layout_for = self.expected
+        self.fired = [False] * len(self.params)
+        self.pending = [len(b) for b in self.buckets]
+        self.next_launch = 0
+        self._works = []
+        for p in self.params:
+            p.grad = None
+        for b, idxs in enumerate(self.buckets):
+            self.flats[b].zero_()
+            off = 0
+            for i in idxs:
+                p = self.params[i]
+                p.grad = self.flats[b][off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self._active = True
+
+    _layout_for = object()
+
+    # -- during backward -------------------------------------------------------------------------------------------
+    def _launch_ready(self, force=False):
+        while self.next_launch < len(self.buckets) and (force or self.pending[self.next_launch] == 0):
+            flat = self.flats[self.next_launch]
+            gloo = _is_gloo(self.part.group)
+            if flat.is_cuda and gloo:                           # rehearsal: synchronous, staged
+                self.part.all_reduce_sum(flat)
+            else:
+                self._works.append(dist.all_reduce(flat, group=self.part.group, async_op=True))
+            self.next_launch += 1
+
+    def _on_grad(self, p):
+        if not self._active:
+            return
+        i = self.index[id(p)]
+        self.fired[i] = True
+        b = self.bucket_of.get(i)
+        if b is None or self.expected is None:
+            return                                              # first step (learning) / unexpected gradient: handled in finish()
+        self.pending[b] -= 1
+        self._launch_ready()
+
+    # -- after backward --------------------------------------------------------------------------------------------
+    def finish(self):
+        part = self.part
+        self._active = False
+        self._launch_ready(force=True)                          # whatever is left, in bucket order
+        for w in self._works:
+            w.wait()
+        self._works = []
+        if self.expected is None:
+            # learning step: vote on "some rank has a gradient for it"; the others go back to grad = None
+            has = torch.tensor([1.0 if f else 0.0 for f in self.fired])
+            if has.numel():
+                part.all_reduce_max(has)
+            self.expected = [bool(v > 0.5) for v in has.tolist()]
+            for p, keep in zip(self.params, self.expected):
+                if not keep:
+                    p.grad = None
+            return
+        # steady state: did any rank get a gradient for a parameter outside the learned set?
+        stray = [i for i, p in enumerate(self.params) if not self.expected[i] and p.grad is not None]
+        flag = torch.tensor([1.0 if stray else 0.0])
+        part.all_reduce_max(flag)
+        if float(flag) > 0.5:
+            has = torch.tensor([1.0 if (not e and p.grad is not None) else 0.0 for p, e in zip(self.params, self.expected)])
+            part.all_reduce_max(has)
+            for i, v in enumerate(has.tolist()):
+                if v > 0.5:
+                    p = self.params[i]
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                    part.all_reduce_sum(p.grad)
+            self.expected = None                                # learn the set again on the next step
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+
 class PartitionContext:
     """Attached to ``GraphTextLM.dist``; owns the plan, the local CSR and the collectives."""
 
@@ -196,6 +458,8 @@ class PartitionContext:
         self.ranges = [row_range(plan.n_total, plan.world, r) for r in range(plan.world)]
         self.send_idx = plan.send_idx.to(self.device)
         self.csr = None
+        self.use_ring = False            # CrossAttention: ring K|V exchange instead of the K|V all-gather
+        self._halo_pending = []
 
     def build_csr(self, num_relations: int):
         from .graph import build_rel_csr
@@ -206,8 +470,18 @@ class PartitionContext:
         return self.csr
 
     # -- exchange steps ---------------------------------------------------------------------
-    def with_halo(self, x: torch.Tensor) -> torch.Tensor:
-        return _HaloExchange.apply(x, self)
+    def with_halo(self, x: torch.Tensor, defer: bool = False) -> torch.Tensor:
+        """``defer=True``: the exchange is only STARTED; rows [n_local, n_local + n_halo) of the result are valid
+        after ``wait_halo()`` (the caller puts independent work in between)."""
+        return _HaloExchange.apply(x, self, defer)
+
+    def wait_halo(self) -> None:
+        while self._halo_pending:
+            work, _send = self._halo_pending.pop()
+            work.wait()
+
+    def ring_attention(self, q: torch.Tensor, kv: torch.Tensor, num_heads: int, block, seed: int = 0) -> torch.Tensor:
+        return _RingAttention.apply(q, kv, self, num_heads, block, seed)
 
     def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
         """In-place all-reduce of ``t`` wherever it lives: gloo has no device collectives (device tensors are staged
@@ -237,6 +511,14 @@ class PartitionContext:
 
     def local_rows(self, t: torch.Tensor) -> torch.Tensor:
         return t[self.plan.lo:self.plan.hi]
+
+    def grad_buckets(self, module: torch.nn.Module, bucket_bytes: int = 256 << 20) -> "GradBuckets":
+        """The overlapping, copy-free gradient reducer for ``module`` (created once, cached on the module)."""
+        gb = getattr(module, "_gmlm_grad_buckets", None)
+        if gb is None or gb.part is not self:
+            gb = GradBuckets(self, module, bucket_bytes)
+            module._gmlm_grad_buckets = gb
+        return gb
 
     def all_reduce_grads(self, module: torch.nn.Module, bucket_bytes: int = 256 << 20) -> None:
         """Sum replicated parameter gradients over ranks in a few large flat buckets (xGMI is per-link

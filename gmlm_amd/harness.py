@@ -136,10 +136,12 @@ def pretrain_step(model, optimizer, x, edge_index, mask1, mask2, *, beta=0.7, te
     (finite,) = _all_flags(model, bool(torch.isfinite(loss)))
     if not finite:
         return float(loss)
+    if model.dist is not None:
+        model.dist.grad_buckets(model).prepare()          # gradients as views of flat buckets, reduced under backward
     loss.backward()
     scale = 1.0
     if model.dist is not None:
-        model.dist.all_reduce_grads(model)
+        model.dist.grad_buckets(model).finish()
         scale = float(model.dist.plan.world)
     optimizer.step()
     return float(loss.detach()) * scale
@@ -198,9 +200,11 @@ def train_step(model, optimizer, scheduler, x, edge_index, texts, y, active_mask
     (finite,) = _all_flags(model, bool(torch.isfinite(loss)))
     if not finite:
         return StepResult(float(loss_value), acc, True)
+    if dist_ctx is not None:
+        dist_ctx.grad_buckets(model).prepare()            # gradients as views of flat buckets, reduced under backward
     loss.backward()
     if dist_ctx is not None:
-        dist_ctx.all_reduce_grads(model)
+        dist_ctx.grad_buckets(model).finish()
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=grad_clip_norm)
     optimizer.step()
     if scheduler is not None:

@@ -117,8 +117,9 @@ class GraphTextLM(nn.Module):
     def _block(self, k: int, x: torch.Tensor, csr: RelCSR) -> torch.Tensor:
         conv, norm, drop = getattr(self, f"rgcn{k}"), getattr(self, f"gnorm{k}"), getattr(self, f"dropout{k}")
         if self.dist is not None:
-            x = self.dist.with_halo(x)                                # [n_local + n_halo, F]
-        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None)   # [n, out] in cd
+            x = self.dist.with_halo(x, defer=True)                    # [n_local + n_halo, F]; halo rows land under the root GEMM
+        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None,
+                             self.dist.wait_halo if self.dist is not None else None)                 # [n, out] in cd
         cd = x.dtype
         n_total = self.dist.n_total if self.dist is not None else z.size(0)
         if n_total > 1:                                               # main.py:273 guard
@@ -265,10 +266,11 @@ class GraphTextLM(nn.Module):
         cd = self._cd()
         g = gnn_embeds.unsqueeze(0)
         t = plm_embeds.unsqueeze(0)
-        gather = self.dist.all_gather_rows if self.dist is not None else None
+        ring = self.dist.ring_attention if (self.dist is not None and self.dist.use_ring) else None
+        gather = self.dist.all_gather_rows if (self.dist is not None and ring is None) else None
         self.graph_to_text_attn.compute_dtype = self.text_to_graph_attn.compute_dtype = cd
-        gnn_attended = self.graph_to_text_attn(g, t, gather)
-        text_attended = self.text_to_graph_attn(t, g, gather)
+        gnn_attended = self.graph_to_text_attn(g, t, gather, ring)
+        text_attended = self.text_to_graph_attn(t, g, gather, ring)
         fn = self.fusion_network
         pdim = gnn_attended.shape[-1]
         w = fn[0].weight

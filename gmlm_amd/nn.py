@@ -122,17 +122,24 @@ class RGCNConv(nn.Module):
             w = F.pad(w, (0, 0, 0, in_pad))
         return w.reshape(-1, self.out_channels).to(dtype)
 
-    def forward_csr(self, x: torch.Tensor, csr: RelCSR, reducer=None) -> torch.Tensor:
+    def forward_csr(self, x: torch.Tensor, csr: RelCSR, reducer=None, halo_wait=None) -> torch.Tensor:
         """x: [n_src, in (+pad)] in the compute dtype -> [n, out] in the same dtype (two accumulating
-        hipBLASLt GEMMs: bias + H W_cat, then += x root; no fp32 staging passes over [n, out])."""
+        hipBLASLt GEMMs: bias + x root, then += H W_cat; no fp32 staging passes over [n, out]).
+
+        Node partition: rows [n, n_src) of x are halo rows whose all-to-all may still be in flight; the root GEMM
+        (owned rows only) and the basis composition run first, ``halo_wait()`` is called right before the
+        aggregation, so the exchange hides under them."""
         in_pad = x.shape[1] - self.in_channels
         n = csr.num_nodes
-        h = ops.RGCNAggregate.apply(x, csr)                                   # [n, R_a*(in+pad)]
         with torch.autocast("cuda", enabled=False):
             w = self.relation_weights(csr, x.dtype, in_pad, reducer)
             root = self.root if not in_pad else F.pad(self.root, (0, 0, 0, in_pad))
-            out = torch.addmm(self.bias.to(x.dtype), h, w)
-            return out.addmm_(x[:n], root.to(x.dtype))
+            out = torch.addmm(self.bias.to(x.dtype), x[:n], root.to(x.dtype))
+        if halo_wait is not None:
+            halo_wait()
+        h = ops.RGCNAggregate.apply(x, csr)                                   # [n, R_a*(in+pad)]
+        with torch.autocast("cuda", enabled=False):
+            return out.addmm_(h, w)
 
     def forward(self, x, edge_index, edge_type):
         csr = _GRAPHS.get(edge_index, x.size(0), self.num_relations, edge_type)
@@ -177,11 +184,12 @@ class CrossAttention(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.compute_dtype: Optional[torch.dtype] = None
 
-    def forward(self, x, y, kv_gather=None):
+    def forward(self, x, y, kv_gather=None, ring=None):
         """x: [B, N, C] queries, y: [B, M, C] keys/values (the reference calls it with B == 1).
 
-        ``kv_gather``: optional callable mapping the local [B, M, 2C] K|V projection to the global one
-        (all-gather over the node partition)."""
+        Node partition: ``kv_gather`` maps the local [B, M, 2C] K|V projection to the
+        global one (all-gather, small graphs); ``ring(q, kv, num_heads, block, seed)`` instead runs the ring
+        exchange with carried online-softmax state (gmlm_amd.dist.PartitionContext.ring_attention)."""
         cd = compute_dtype(self.compute_dtype)
         b, n, c = x.shape
         xq, yk = x.to(cd), y.to(cd)
@@ -189,6 +197,10 @@ class CrossAttention(nn.Module):
         wkv = torch.cat([self.k_proj.weight, self.v_proj.weight], 0)
         bkv = torch.cat([self.k_proj.bias, self.v_proj.bias], 0)
         kv = _linear(yk, wkv, bkv)                                    # [B, M, 2C] fused K|V
+        if ring is not None:
+            p = self.dropout.p if self.training else 0.0
+            o = ring(q, kv, self.num_heads, ops.AttentionBlock(self.num_heads, self.scale, p), ops.draw_seed() if p > 0 else 0)
+            return _linear(o, self.out_proj.weight, self.out_proj.bias)
         if kv_gather is not None:
             kv = kv_gather(kv)
         o = attention_any_dim(q, kv[..., :c], kv[..., c:], None, self.num_heads, self.scale, self.dropout.p, self.training)

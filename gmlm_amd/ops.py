@@ -440,6 +440,44 @@ class AttentionQKV(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None, None
 
 
+class AttentionBlock:
+    """Per-block arithmetic of the ring K|V exchange (gmlm_amd.dist._RingAttention) on the HIP kernels, outside
+    autograd: ``fwd`` returns the block's normalised output and its log-sum-exp; ``bwd`` evaluates the block's share of
+    dQ / dK / dV from the GLOBAL output and log-sum-exp (P is recomputed as exp(S - lse_global), delta = rowsum(dO * O))."""
+
+    def __init__(self, num_heads: int, scale: float, dropout_p: float = 0.0):
+        self.h, self.scale, self.p = num_heads, float(scale), float(dropout_p)
+
+    def fwd(self, q, k, v, kv_len, seed):
+        _cuda(q, k, v)
+        b, lq, hd = q.shape
+        lk, d = k.shape[1], hd // self.h
+        if d not in (64, 96):
+            raise NotImplementedError("ring attention needs a native head dim (64 or 96)")
+        out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
+        lse = torch.empty(b, self.h, lq, dtype=torch.float32, device=q.device)
+        with _span("attn_fwd_d%d" % d, flops=4.0 * b * self.h * lq * lk * d):
+            check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, self.h, lq, lk, d, _rows_view(q, self.h, d),
+                                           _rows_view(k, self.h, d), _rows_view(v, self.h, d), self.scale, self.p, int(seed),
+                                           _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
+        return out, lse
+
+    def bwd(self, q, k, v, out, dout, lse, kv_len, seed):
+        b, lq, hd = q.shape
+        lk, d = k.shape[1], hd // self.h
+        dq = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
+        dk = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
+        dv = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
+        ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, self.h, lq, lk, d), q.device)
+        out, dout, lse = out.contiguous(), dout.contiguous(), lse.contiguous()
+        with _span("attn_bwd_d%d" % d, flops=10.0 * b * self.h * lq * lk * d):
+            check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(kv_len), b, self.h,
+                                           lq, lk, d, _rows_view(q, self.h, d), _rows_view(k, self.h, d), _rows_view(v, self.h, d),
+                                           self.scale, self.p, int(seed), _ptr(dq), _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0,
+                                           _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
+        return dq, dk, dv
+
+
 def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0, pair_count=None):
     p = float(dropout_p) if training else 0.0
     return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len, pair_count)

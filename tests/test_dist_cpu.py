@@ -114,3 +114,168 @@ def test_partition_shard_files_round_trip(tmp_path):
     np.savez(tmp_path / "bad2.npz", **bad)
     with pytest.raises(ValueError):
         gd.load_partition(str(tmp_path / "bad2.npz"))
+
+
+class _TorchBlock:
+    """torch (float64) restatement of the per-block attention arithmetic the ring exchange is built on — the checker's
+    stand-in for gmlm_amd.ops.AttentionBlock (HIP kernels), same contract: fwd -> (normalised block output, block
+    log-sum-exp), bwd -> the block's share of dQ / dK / dV given the GLOBAL output and log-sum-exp."""
+
+    def __init__(self, h, scale):
+        self.h, self.scale = h, scale
+
+    def _heads(self, t):
+        b, l, c = t.shape
+        return t.view(b, l, self.h, c // self.h).transpose(1, 2)                       # [b, h, l, d]
+
+    def fwd(self, q, k, v, kv_len, seed):
+        s = torch.matmul(self._heads(q), self._heads(k).transpose(-1, -2)) * self.scale
+        keep = torch.arange(k.shape[1])[None, None, None, :] < kv_len.view(-1, 1, 1, 1)
+        s = s.masked_fill(~keep, float("-inf"))
+        lse = torch.logsumexp(s, -1)
+        o = torch.matmul(torch.exp(s - lse.unsqueeze(-1)), self._heads(v))
+        return o.transpose(1, 2).reshape(q.shape), lse
+
+    def bwd(self, q, k, v, out, dout, lse, kv_len, seed):
+        qh, kh, vh, oh, gh = (self._heads(t) for t in (q, k, v, out, dout))
+        s = torch.matmul(qh, kh.transpose(-1, -2)) * self.scale
+        keep = torch.arange(k.shape[1])[None, None, None, :] < kv_len.view(-1, 1, 1, 1)
+        p = torch.exp(s - lse.unsqueeze(-1)).masked_fill(~keep, 0.0)                   # GLOBAL lse: P is the global softmax restricted to the block
+        dv = torch.matmul(p.transpose(-1, -2), gh)
+        delta = (gh * oh).sum(-1, keepdim=True)
+        ds = p * (torch.matmul(gh, vh.transpose(-1, -2)) - delta) * self.scale
+        back = lambda t: t.transpose(1, 2).reshape(t.shape[0], t.shape[2], -1)         # noqa: E731
+        return back(torch.matmul(ds, kh)), back(torch.matmul(ds.transpose(-1, -2), qh)), back(dv)
+
+
+def _ring_worker(rank, world, port, n, c, h):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gmlm_amd.dist import PartitionContext, plan_partition
+        g = torch.Generator().manual_seed(21)
+        ei = torch.randint(0, n, (2, 4 * n), generator=g)
+        q_all = torch.randn(1, n, c, generator=g, dtype=torch.float64)
+        kv_all = torch.randn(1, n, 2 * c, generator=g, dtype=torch.float64) * 1.5
+        go_all = torch.randn(1, n, c, generator=g, dtype=torch.float64)
+        ctx = PartitionContext(plan_partition(ei, n, world, rank), "cpu")
+        lo, hi = ctx.plan.lo, ctx.plan.hi
+        blk = _TorchBlock(h, (c // h) ** -0.5)
+        # reference 1: the all-gather path on the same ranks
+        q1 = q_all[:, lo:hi].clone().requires_grad_(True)
+        kv1 = kv_all[:, lo:hi].clone().requires_grad_(True)
+        full = ctx.all_gather_rows(kv1)
+        o1, _ = blk.fwd(q1, full[..., :c], full[..., c:], torch.tensor([n]), 0)
+        o1.backward(go_all[:, lo:hi])
+        # reference 2: single process, all rows
+        qa, kva = q_all.clone().requires_grad_(True), kv_all.clone().requires_grad_(True)
+        oa, _ = blk.fwd(qa, kva[..., :c], kva[..., c:], torch.tensor([n]), 0)
+        oa.backward(go_all)
+        # ring
+        q2 = q_all[:, lo:hi].clone().requires_grad_(True)
+        kv2 = kv_all[:, lo:hi].clone().requires_grad_(True)
+        o2 = ctx.ring_attention(q2, kv2, h, blk)
+        o2.backward(go_all[:, lo:hi])
+        for a, b_, name in ((o2, o1, "out"), (q2.grad, q1.grad, "dq"), (kv2.grad, kv1.grad, "dkv"),
+                            (o2, oa[:, lo:hi], "out vs 1-process"), (q2.grad, qa.grad[:, lo:hi], "dq vs 1-process"),
+                            (kv2.grad, kva.grad[:, lo:hi], "dkv vs 1-process")):
+            assert torch.allclose(a.detach(), b_.detach(), rtol=1e-10, atol=1e-11), (rank, name, float((a - b_).abs().max()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 37), (3, 50), (4, 10)])
+def test_ring_attention_matches_all_gather(world, n):
+    """Ring K|V exchange with carried online-softmax state == K|V all-gather == one process (float64, 1e-10), forward
+    and all three gradients, uneven row shares (padded blocks masked by their true length)."""
+    port = 36000 + (os.getpid() % 2000) + world
+    mp.spawn(_ring_worker, args=(world, port, n, 12, 3), nprocs=world, join=True)
+
+
+def _bucket_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gmlm_amd.dist import PartitionContext, plan_partition
+        torch.manual_seed(0)                                    # same parameters on every rank (replicated)
+
+        class Net(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.a, self.b, self.c = torch.nn.Linear(6, 5), torch.nn.Linear(5, 4), torch.nn.Linear(4, 3)
+                self.text = torch.nn.Linear(6, 3)               # used only by ranks that have "active text rows"
+                self.dead = torch.nn.Linear(3, 3)               # never used by anyone: must keep grad = None
+
+            def forward(self, x, use_text):
+                y = self.c(torch.relu(self.b(torch.relu(self.a(x)))))
+                return y + self.text(x) if use_text else y
+
+        net = Net()
+        ctx = PartitionContext(plan_partition(torch.randint(0, 8, (2, 16)), 8, world, rank), "cpu")
+        gb = ctx.grad_buckets(net, bucket_bytes=64)             # several tiny buckets
+        g = torch.Generator().manual_seed(100 + rank)
+        for step in range(4):
+            x = torch.randn(7, 6, generator=g)
+            use_text = rank == 0 or step == 3                   # rank 0 always; the others only on the last step
+            gb.prepare()
+            net(x, use_text).square().sum().backward()
+            gb.finish()
+            # the same sum computed the plain way
+            ref = Net()
+            ref.load_state_dict(net.state_dict())
+            ref(x, use_text).square().sum().backward()
+            for (k, p), (_, pr) in zip(net.named_parameters(), ref.named_parameters()):
+                local = torch.zeros_like(pr) if pr.grad is None else pr.grad.clone()
+                dist.all_reduce(local)
+                if k.startswith("dead"):
+                    assert p.grad is None, (step, k)
+                else:
+                    assert p.grad is not None and torch.allclose(p.grad, local, rtol=1e-6, atol=1e-6), (rank, step, k)
+            if step >= 1:                                       # learned set: gradients are views of the flat buckets (no copies)
+                assert all(p.grad.data_ptr() >= f.data_ptr() and p.grad.data_ptr() < f.data_ptr() + f.numel() * 4
+                           for i, p in enumerate(gb.params) if gb.expected[i] for f in [gb.flats[gb.bucket_of[i]]])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_buckets_overlap_matches_plain_sum(world):
+    """Flat-buffer gradient buckets launched from backward hooks: same sums as a plain all-reduce when the ranks'
+    gradients become final at different times / not at all (a rank that never touches the text branch), and a
+    parameter no rank uses keeps grad = None."""
+    port = 38000 + (os.getpid() % 2000) + world
+    mp.spawn(_bucket_worker, args=(world, port), nprocs=world, join=True)
+
+
+def _halo_overlap_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gmlm_amd.dist import PartitionContext, plan_partition
+        n, e, f = 83, 600, 5
+        g = torch.Generator().manual_seed(3)
+        ei = torch.randint(0, n, (2, e), generator=g)
+        x = torch.randn(n, f, generator=g)
+        ctx = PartitionContext(plan_partition(ei, n, world, rank), "cpu")
+        lo, hi = ctx.plan.lo, ctx.plan.hi
+        outs = []
+        for overlap in (False, True):
+            xl = x[lo:hi].clone().requires_grad_(True)
+            xh = ctx.with_halo(xl, defer=overlap)
+            local_work = xl @ torch.ones(f, 2)                  # what RGCNConv does meanwhile: the root GEMM on owned rows
+            assert (len(ctx._halo_pending) > 0) == overlap      # deferred only when asked
+            ctx.wait_halo()
+            assert torch.equal(xh[ctx.plan.n_local:].detach(), x[ctx.plan.halo_ids])
+            (xh.sum() * 2 + local_work.sum()).backward()
+            outs.append((xh.detach().clone(), xl.grad.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # bit for bit
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_deferred_wait_is_bit_identical():
+    port = 39000 + (os.getpid() % 2000)
+    mp.spawn(_halo_overlap_worker, args=(3, port), nprocs=3, join=True)

@@ -143,7 +143,83 @@ def test_bf16_training_reduces_loss_on_learnable_labels():
         losses.append(r.loss)
     assert np.mean(losses[-5:]) < 0.8 * np.mean(losses[:5]), losses
     # eval mode (dropout off, no soft mask) on the nodes it was trained on: the labels have been fitted.  Held-out
-    # accuracy is NOT asserted: on this random graph it depends on the init (tests/diag_generalize.py: 0.24-0.92
-    # for the same protocol, and the CPU oracle gives the same 40-step trajectory as the fp32 path to 3 decimals).
+    # accuracy depends on the (random) init on this graph, 0.24-0.92 for the same protocol, so it is not asserted HERE;
+    # test_forty_step_trajectory_matches_oracle_and_bf16_tracks_fp32 below pins the protocol instead: loss trajectory
+    # and train / held-out accuracy equal to the CPU oracle's, bf16 within a stated budget of fp32.
     loss, acc, f1 = harness.eval_step(m, xd, eid, tokens, yd, td, plm_batch_size=4096)
     assert np.isfinite(loss) and acc > 0.8 and f1 > 0.8
+
+
+def test_forty_step_trajectory_matches_oracle_and_bf16_tracks_fp32():
+    """The evidence behind the sanity test above, as an assertion: the SAME 40-step protocol (learnable labels, fixed
+    masks, AdamW with the reference's three groups, clip, warm-up; dropout 0 so that the CPU oracle can follow) gives
+    the same loss trajectory on the fp32 HIP path as on the CPU oracle, the same train / held-out accuracy afterwards,
+    and the bf16 path tracks the fp32 one within a bf16 budget.  A bf16 / optimiser / backward bug that merely slows
+    learning down would pass ``loss drops``; it does not pass this."""
+    import gmlm_amd
+    from gmlm_amd import harness
+    from test_gpu_model import build_model
+    dev = torch.device("cuda:0")
+    plm = dict(hidden=128, layers=2, heads=2, inter=256, max_pos=64, vocab=200)
+    n, e, f_in, c = 600, 4000, 64, 4
+    cfg = dict(n=n, e=e, f_in=f_in, hc=32, c=c, plm=plm, seed=31, max_len=16)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(n, f_in, generator=g)
+    proto = torch.randn(c, f_in, generator=g)
+    y = (x @ proto.t()).argmax(1)
+    ei = torch.randint(0, n, (2, e), generator=g)
+    ids, am = O.synthetic_tokens(n, 16, 200, 3, 4)
+    ids[:, 1] = 5 + y
+    train = torch.zeros(n, dtype=torch.bool)
+    train[: n // 2] = True
+    masks = []
+    for _ in range(40):
+        mk = torch.zeros(n, dtype=torch.bool)
+        mk[torch.randperm(n // 2, generator=g)[:180]] = True
+        masks.append(mk)
+    lrs = dict(lr_graph=3e-3, lr_bert=3e-4, lr_other=3e-3, weight_decay=0.01)
+
+    # CPU oracle: the same loop as main.py:528-563
+    om, _ = oracle_model_from_config(cfg)
+    groups = [[], [], []]
+    for name, p in om.named_parameters():
+        groups[1 if name.startswith("plm_params.") else (0 if any(s in name for s in harness.GNN_PARAM_NAMES) else 2)].append(p)
+    oopt = torch.optim.AdamW([{"params": groups[0], "lr": 3e-3, "weight_decay": 0.01}, {"params": groups[1], "lr": 3e-4, "weight_decay": 0.01},
+                              {"params": groups[2], "lr": 3e-3, "weight_decay": 0.01}])
+    osched = harness.linear_warmup_schedule(oopt, 3, 60)
+    ref = []
+    for mk in masks:
+        oopt.zero_grad()
+        loss = F.cross_entropy(om(O.soft_masking_gnn_input(x, mk, om.gnn_mask_token_embed, 0.7), ei, ids, am, mk, plm_batch_size=4096)[mk],
+                               y[mk], label_smoothing=0.2)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(om.parameters(), 1.0)
+        oopt.step(); osched.step()
+        ref.append(float(loss.detach()))
+    with torch.no_grad():
+        om.eval()
+        ref_acc = {}
+        for nm, msk in (("train", train), ("held", ~train)):
+            ref_acc[nm] = float((om(x, ei, ids, am, msk, plm_batch_size=4096)[msk].argmax(1) == y[msk]).float().mean())
+
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    xd, eid, yd = x.to(dev), ei.to(dev), y.to(dev)
+
+    def run(autocast):
+        m = build_model(cfg, dev)
+        opt = harness.setup_optimizer(m, **lrs)
+        sched = harness.linear_warmup_schedule(opt, 3, 60)
+        traj = [harness.train_step(m, opt, sched, xd, eid, tokens, yd, mk.to(dev), plm_batch_size=4096, autocast=autocast).loss for mk in masks]
+        acc = {nm: harness.eval_step(m, xd, eid, tokens, yd, msk.to(dev), plm_batch_size=4096, autocast=autocast)[1]
+               for nm, msk in (("train", train), ("held", ~train))}
+        return np.array(traj), acc
+
+    t32, a32 = run(False)
+    print(f"\n40 steps: oracle {ref[0]:.4f} -> {ref[-1]:.4f}, fp32 HIP max|d| {np.abs(t32 - np.array(ref)).max():.2e}; acc oracle {ref_acc} fp32 {a32}")
+    assert ref[-1] < 0.8 * ref[0]                                     # the protocol does learn
+    np.testing.assert_allclose(t32, ref, rtol=0, atol=1e-3)          # same trajectory (measured: 1.3e-6 over all 40 steps)
+    assert abs(a32["train"] - ref_acc["train"]) <= 0.01 and abs(a32["held"] - ref_acc["held"]) <= 0.02, (a32, ref_acc)
+    tbf, abf = run(True)
+    print(f"bf16 vs fp32 trajectory max|d| {np.abs(tbf - t32).max():.2e}; acc bf16 {abf}")
+    np.testing.assert_allclose(tbf, t32, rtol=0, atol=2e-2)           # 8-bit mantissa operands, 40 optimiser steps (measured: 6.6e-3)
+    assert abs(abf["train"] - a32["train"]) <= 0.03 and abs(abf["held"] - a32["held"]) <= 0.05, (abf, a32)

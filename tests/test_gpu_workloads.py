@@ -1,0 +1,192 @@
+"""Parity ON the benchmarked workloads (BASELINE.json configs[2] and configs[3]) — not on scaled-down stand-ins.
+
+* Squirrel-size (N=5,201, E=217,073, F_in=2089), hidden_channels=768, BERT-base geometry (768 / 12 layers / 12 heads /
+  3072): the model ``bench.py`` times.  Full GraphTextLM forward + backward, fp32 HIP path vs the CPU oracle (north_star:
+  logits within 1e-4), and the bench's bf16 path vs the fp32 HIP path with a stated budget.  The active set is cut to
+  128 nodes with <= 32 tokens so the CPU oracle leg stays around a minute; the GNN, both N x N cross-attentions and the
+  head run at full size.
+* the same graph size with power-law (Chung-Lu) edges, so that all four degree buckets occur (R_a = 4: the
+  relation-segmented layout, the one-GEMM H.W_cat form and the R_a > 1 basis composition at hidden_channels=768).
+* ogbn-arxiv size (N=169,343, E=1,166,243, F_in=128, C=40) on ONE GPU: the reference cannot run this at all (its dense
+  [1,8,N,N] scores need 918 GB, main.py:159-160); the GNN is checked against the oracle, the streaming cross-attention
+  against a dense fp32 evaluation of a row subset, the full forward for finiteness and bit-determinism.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import gmlm_oracle as O
+from helpers import oracle_model_from_config
+from test_gpu_model import build_model
+
+pytestmark = pytest.mark.gpu
+
+BERT_BASE = dict(hidden=768, layers=12, heads=12, inter=3072, max_pos=512, vocab=30522)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _grad_report(named_hip, og, rel, floor):
+    worst = (0.0, "")
+    for k, p in named_hip:
+        ok = "plm_params." + k[len("plm_encoder."):].replace(".", "/") if k.startswith("plm_encoder.") else k
+        r = og.get(ok)
+        if r is None or p.grad is None:
+            assert (r is None or float(r.abs().max()) == 0) and (p.grad is None or float(p.grad.abs().max()) == 0), k
+            continue
+        rn, gn = float(r.double().norm()), float(p.grad.double().norm())
+        err = abs(rn - gn) / max(rn, floor)
+        worst = max(worst, (err, k))
+        assert err <= rel, (k, gn, rn)
+    return worst
+
+
+def test_squirrel_h768_bert_base_fp32_vs_oracle_and_bf16_budget(dev):
+    import gmlm_amd
+    n, e, f_in, c = O.WORKLOADS["squirrel"]
+    cfg = dict(n=n, e=e, f_in=f_in, hc=768, c=c, plm=BERT_BASE, seed=768, max_len=32)
+    data = O.synthetic_graph("squirrel")
+    csr_types = O.edge_types_from_degree(data["edge_index"], n)
+    assert int(csr_types.min()) == 3                      # uniform edges at mean out-degree 41.7: every edge in bucket 3 (R_a = 1)
+    ids, am = O.synthetic_tokens(n, 32, BERT_BASE["vocab"], seed=n, min_len=8)
+    act = data["active_mask"].nonzero().reshape(-1)[:128]  # 128 active nodes: the oracle's BERT leg stays small
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[act] = True
+    om, _ = oracle_model_from_config(cfg)
+    xm_ref = O.soft_masking_gnn_input(data["x"], mask, om.gnn_mask_token_embed, 0.7)
+    ref = om(xm_ref, data["edge_index"], ids, am, mask, plm_batch_size=128)
+    loss_ref = F.cross_entropy(ref[mask], data["y"][mask], label_smoothing=0.2)
+    loss_ref.backward()
+    og = {k: p.grad for k, p in om.named_parameters()}
+
+    def run(cd):
+        m = build_model(cfg, dev, compute_dtype=cd).train()
+        x, ei, mk = data["x"].to(dev), data["edge_index"].to(dev), mask.to(dev)
+        tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+        logits = m(m.soft_mask_input(x, mk, 0.7), ei, tokens, mk, plm_batch_size=128)
+        loss = F.cross_entropy(logits[mk], data["y"].to(dev)[mk], label_smoothing=0.2)
+        loss.backward()
+        return m, logits.detach().float().cpu(), float(loss)
+
+    m32, l32, loss32 = run(torch.float32)
+    err = float((l32 - ref.detach()).abs().max())
+    assert err <= 1e-4, f"fp32 logits differ from the oracle by {err}"            # north_star tolerance, on the bench workload
+    assert abs(loss32 - float(loss_ref)) <= 1e-4
+    # floor 1e-3: the key biases' gradients are analytically zero under softmax (pure rounding noise, ~4e-7 at N = 5,201)
+    worst = _grad_report(m32.named_parameters(), og, 2e-3, 1e-3)
+    g32 = {k: p.grad.detach().double().cpu() for k, p in m32.named_parameters() if p.grad is not None}
+    del m32
+    torch.cuda.empty_cache()
+    # bf16 (the dtype bench.py reports) against the fp32 HIP path on the same inputs.  Budget: every GEMM / attention
+    # operand is rounded to 8 mantissa bits (relative 2^-9), accumulation and normalisation statistics stay fp32; through
+    # 4 RGCN + 12 BERT + 2 cross-attention + 3 head layers the roundings add like a random walk: ~2^-9 * sqrt(21 layers
+    # * ~3 roundings) * |activation scale ~2| ~ 3e-2 on logits of O(1).
+    mbf, lbf, lossbf = run(torch.bfloat16)
+    d = (lbf - l32).abs()
+    print(f"\nsquirrel h768: fp32 vs oracle max|dlogit| = {err:.2e} (worst grad-norm rel err {worst[0]:.2e} at {worst[1]}); "
+          f"bf16 vs fp32: max {float(d.max()):.3e} mean {float(d.mean()):.3e} dloss {abs(lossbf - loss32):.3e}")
+    assert float(d.max()) <= 3e-2 and float(d.mean()) <= 6e-3 and abs(lossbf - loss32) <= 5e-3   # measured: 1.05e-2 / 2.5e-3 / 9e-4
+    # gradients: direction (cosine) and size against the fp32 path, per parameter tensor.  Tensors whose fp32 gradient
+    # is tiny against the model's gradient scale (the query / key projections of a random-init encoder: the softmax is
+    # nearly flat, dS ~ 0) are rounding-dominated in ANY reduced precision; they are held to an absolute error of 1 % of
+    # the largest per-tensor gradient norm instead of a relative one.
+    rows = []
+    for k, p in mbf.named_parameters():
+        if p.grad is None or k not in g32:
+            continue
+        a, b = p.grad.detach().double().cpu().reshape(-1), g32[k].reshape(-1)
+        rows.append((k, float(b.norm()), float(a.norm()), float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30)), float((a - b).norm())))
+    gmax = max(r[1] for r in rows)
+    big = [r for r in rows if r[1] >= 1e-2 * gmax]
+    small = [r for r in rows if r[1] < 1e-2 * gmax]
+    worst_cos = min(big, key=lambda r: r[3])
+    worst_ratio = max(big, key=lambda r: abs(r[2] / r[1] - 1))
+    worst_abs = max(small, key=lambda r: r[4]) if small else None
+    print(f"bf16 gradients vs fp32 ({len(big)} tensors with norm >= 1% of the largest, {gmax:.3e}): min cosine {worst_cos[3]:.4f} at {worst_cos[0]}, "
+          f"worst |norm ratio - 1| {abs(worst_ratio[2] / worst_ratio[1] - 1):.3f} at {worst_ratio[0]}; "
+          + (f"{len(small)} small tensors: worst |diff| {worst_abs[4]:.2e} = {worst_abs[4] / gmax:.2e} of the largest norm at {worst_abs[0]}" if small else ""))
+    for r in sorted(rows, key=lambda r: r[3])[:6]:
+        print(f"    {r[0]:60s} |g32| {r[1]:.3e} |gbf| {r[2]:.3e} cos {r[3]:.4f} |diff| {r[4]:.2e}")
+    assert worst_cos[3] >= 0.999, worst_cos                                   # measured: 0.9999
+    assert abs(worst_ratio[2] / worst_ratio[1] - 1) <= 0.03, worst_ratio      # measured: 0.011
+    assert worst_abs is None or worst_abs[4] <= 2e-3 * gmax, worst_abs        # measured: 1.6e-4
+
+
+def _chung_lu(n, e, seed):
+    g = torch.Generator().manual_seed(seed)
+    w = (torch.arange(n, dtype=torch.float32) + 1).pow(-1.0 / 1.2)                   # alpha = 2.2 (SURVEY section 8d, S5 generator)
+    perm = torch.randperm(n, generator=g)
+    return torch.stack([perm[torch.multinomial(w, e, True, generator=g)], perm[torch.multinomial(w, e, True, generator=g)]]), g
+
+
+def test_squirrel_size_power_law_h768_all_relations_vs_oracle(dev):
+    """Same N, E, F_in, hidden_channels as the bench, heavy-tailed degrees: R_a = 4 and hub segments (chunked path)."""
+    n, e, f_in, c = O.WORKLOADS["squirrel"]
+    ei, g = _chung_lu(n, e, 4242)
+    x = torch.randn(n, f_in, generator=g)
+    plm = dict(hidden=768, layers=1, heads=12, inter=128, max_pos=64, vocab=200)        # PLM not exercised here
+    cfg = dict(n=n, e=e, f_in=f_in, hc=768, c=c, plm=plm, seed=77)
+    om, _ = oracle_model_from_config(cfg)
+    go = torch.randn(n, 768, generator=g)
+    ref = om.get_graph_embeddings(x, ei)
+    ref.backward(go)
+    m = build_model(cfg, dev).train()
+    csr = m.graph(ei.to(dev), n)
+    assert csr.r_active == 4
+    assert np.array_equal(csr.edge_type.cpu().numpy(), O.edge_types_from_degree(ei, n).numpy())     # bit-exact
+    out = m.get_graph_embeddings(x.to(dev), ei.to(dev))
+    out.backward(go.to(dev))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    worst = _grad_report([(k, p) for k, p in m.named_parameters() if not k.startswith("plm_encoder.")],
+                         {k: p.grad for k, p in om.named_parameters()}, 2e-3, 1e-4)
+    print(f"\npower-law squirrel h768: worst grad-norm rel err {worst[0]:.2e} at {worst[1]}")
+
+
+def test_arxiv_size_single_gpu(dev):
+    import gmlm_amd
+    from gmlm_amd.nn import CrossAttention
+    n, e, f_in, c = O.WORKLOADS["arxiv"]
+    data = O.synthetic_graph("arxiv")
+    plm = dict(hidden=256, layers=4, heads=4, inter=1024, max_pos=64, vocab=2000)       # BERT-mini: P = 256, cross-attention d = 32 -> padded to 64
+    cfg = dict(n=n, e=e, f_in=f_in, hc=128, c=c, plm=plm, seed=169, max_len=24)
+    # (1) GNN vs the oracle, fp32 (the CPU can do this part: no N x N term)
+    om, _ = oracle_model_from_config(cfg)
+    with torch.no_grad():
+        ref = om.get_graph_embeddings(data["x"], data["edge_index"])
+    m = build_model(cfg, dev).eval()
+    x, ei = data["x"].to(dev), data["edge_index"].to(dev)
+    csr = m.graph(ei, n)
+    assert np.array_equal(csr.edge_type.cpu().numpy(), O.edge_types_from_degree(data["edge_index"], n).numpy())
+    with torch.no_grad():
+        gnn = m.get_graph_embeddings(x, ei)
+    np.testing.assert_allclose(gnn.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)
+    # (2) full forward: finite, [N, C] fp32, bit-deterministic
+    ids, am = O.synthetic_tokens(n, 24, plm["vocab"], seed=n, min_len=4)
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    mask = torch.zeros(n, dtype=torch.bool)
+    mask[data["active_mask"].nonzero().reshape(-1)[:4096]] = True
+    mk = mask.to(dev)
+    with torch.no_grad():
+        a = m(x, ei, tokens, mk, plm_batch_size=4096)
+        b = m(x, ei, tokens, mk, plm_batch_size=4096)
+    assert a.shape == (n, c) and a.dtype == torch.float32 and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b)
+    # (3) streaming cross-attention at N = 169,343 vs a dense fp32 evaluation of 64 query rows (main.py:159-163)
+    g = torch.Generator().manual_seed(3)
+    ca = CrossAttention(768, num_heads=8, dropout=0.0).to(dev).eval()
+    xq = torch.randn(1, n, 768, generator=g).to(dev)
+    yk = (torch.randn(1, n, 768, generator=g) * 1.5).to(dev)
+    rows = torch.randperm(n, generator=g)[:64].to(dev)
+    with torch.no_grad():
+        out = ca(xq, yk)
+        q = F.linear(xq[0, rows], ca.q_proj.weight, ca.q_proj.bias).view(64, 8, 96).transpose(0, 1)          # [8, 64, 96]
+        k = F.linear(yk[0], ca.k_proj.weight, ca.k_proj.bias).view(n, 8, 96).permute(1, 2, 0)                # [8, 96, N]
+        v = F.linear(yk[0], ca.v_proj.weight, ca.v_proj.bias).view(n, 8, 96).transpose(0, 1)                 # [8, N, 96]
+        p = torch.softmax(torch.matmul(q.double(), k.double()) * ca.scale, -1)
+        dense = F.linear(torch.matmul(p, v.double()).transpose(0, 1).reshape(64, 768).float(), ca.out_proj.weight, ca.out_proj.bias)
+    np.testing.assert_allclose(out[0, rows].cpu().numpy(), dense.cpu().numpy(), rtol=1e-4, atol=2e-5)
