@@ -372,7 +372,7 @@ def s5_strong(dev, args, world, rank):
     mask = (torch.rand(n, device=dev, generator=gx) < 0.3)[lo:hi]
     r_a = m.graph(ei, n).r_active if part is None else part.csr.r_active
     if part is not None:
-        del ei
+        ei = None                                                      # the partition's CSR replaces the edge list
         torch.cuda.empty_cache()
 
     def step():

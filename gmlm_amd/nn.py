@@ -225,6 +225,50 @@ def attention_any_dim(q, k, v, kv_len, num_heads, scale, dropout_p, training):
     return o.reshape(b, lq, num_heads, dp)[..., :d].reshape(b, lq, hd)
 
 
+class _ScaledProjectionSum(torch.autograd.Function):
+    """acc [N, P] fp32 = sum_k w_k * (emb_k W_k^T + b_k), with the scalar folded into the (small) weight instead of
+    the (large) GEMM output: one [N, P] accumulator and one transient GEMM output are alive at a time, and nothing of
+    size N x P is saved for backward (the straightforward form keeps four fp32 [N, P] products: 12 KB per node, which
+    is what decided whether the 10M-node graph fits on one GPU)."""
+
+    @staticmethod
+    def forward(ctx, weights, cd, *args):
+        k = len(args) // 3
+        embs, ws, bs = args[:k], args[k:2 * k], args[2 * k:]
+        acc = None
+        with torch.autocast("cuda", enabled=False):
+            for i in range(k):
+                t = F.linear(embs[i].to(cd), (ws[i].float() * weights[i]).to(cd))
+                if acc is None:
+                    acc = t.float()
+                else:
+                    acc.add_(t)
+                del t
+            acc.add_(sum(bs[i].float() * weights[i] for i in range(k)))
+        ctx.save_for_backward(weights, *embs, *ws, *bs)
+        ctx.cd, ctx.k = cd, k
+        return acc
+
+    @staticmethod
+    def backward(ctx, g):
+        k, cd = ctx.k, ctx.cd
+        weights = ctx.saved_tensors[0]
+        embs, ws, bs = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:1 + 2 * k], ctx.saved_tensors[1 + 2 * k:]
+        g_cd = g.to(cd)
+        gsum = g.sum(0)
+        d_weights = torch.zeros_like(weights)
+        d_embs, d_ws, d_bs = [], [], []
+        with torch.autocast("cuda", enabled=False):
+            for i in range(k):
+                e = embs[i].to(cd)
+                d_embs.append((g_cd @ (ws[i].float() * weights[i]).to(cd)).to(embs[i].dtype))
+                dws = (g_cd.t() @ e).float()                     # gradient of the scaled weight
+                d_ws.append(dws * weights[i])
+                d_bs.append(gsum * weights[i])
+                d_weights[i] = (dws * ws[i].float()).sum() + (gsum * bs[i].float()).sum()
+        return (d_weights, None, *d_embs, *d_ws, *d_bs)
+
+
 class MultiScaleFusion(nn.Module):
     """main.py:167-180: LayerNorm(sum_k softmax(w)_k * Linear_k(emb_k))."""
 
@@ -238,9 +282,7 @@ class MultiScaleFusion(nn.Module):
     def forward(self, embeddings_list):
         cd = compute_dtype(self.compute_dtype)
         weights = F.softmax(self.scale_weights.float(), dim=0)
-        acc = None
-        for w, proj, emb in zip(weights, self.projections, embeddings_list):
-            t = _linear(emb.to(cd), proj.weight, proj.bias).float() * w
-            acc = t if acc is None else acc + t
+        acc = _ScaledProjectionSum.apply(weights, cd, *embeddings_list, *[p.weight for p in self.projections],
+                                         *[p.bias for p in self.projections])
         ln = self.layer_norm
         return ops.bias_res_layernorm(acc, None, None, ln.weight, ln.bias, ln.eps)
