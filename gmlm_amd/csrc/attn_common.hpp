@@ -24,6 +24,7 @@ struct AttnParams {
   uint32_t drop_thresh;   // attention-probability dropout (0 = off)
   float keep_scale;
   uint64_t seed;
+  uint32_t grid_q, grid_pairs;   // pipelined forward: 1-D grid of grid_q query blocks x grid_pairs (batch, head) pairs
 };
 
 // per-(batch, head) view: padded layout [b, l, ...] or packed layout (cu_seqlens)

@@ -23,6 +23,8 @@
 // what did not pay (3-deep LDS ring, wave stagger, compiler-tracked DMA builtin) is in DESIGN.md section 5.
 #include "attn_common.hpp"
 
+#include <type_traits>
+
 namespace gmlm {
 
 __device__ __forceinline__ float max16(const f32x16& s) {
@@ -62,37 +64,49 @@ template <int D, int NW, bool ISV>
 struct DmaPlan {
   using G = Img<D>;
   static constexpr int PER = G::NDMA / NW;
-  int goff[PER];    // element offset of this lane's source chunk inside a tile: row * stride + 8 * chunk
-  int rowk[PER];    // tile row of the chunk
-  int colk[PER];    // 8 * chunk
+  uint32_t boff[PER];   // BYTE offset of this lane's source chunk inside a tile: 2 * (row * stride + 8 * chunk)
+  __device__ static __forceinline__ void where(int k, int w, int lane, int& row, int& col) {
+    const int idx = 64 * (w + NW * k) + lane, slot = idx % G::CPR;
+    row = idx / G::CPR;
+    int chunk = slot ^ (ISV ? G::fv(row) : G::fk(row));
+    if (chunk >= D / 8) chunk = D / 8 - 1;              // filler slots of the d = 96 image: any valid address
+    col = 8 * chunk;
+  }
   __device__ __forceinline__ void init(int64_t g_stride, int w, int lane) {
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-      const int idx = 64 * (w + NW * k) + lane, row = idx / G::CPR, slot = idx % G::CPR;
-      int chunk = slot ^ (ISV ? G::fv(row) : G::fk(row));
-      if (chunk >= D / 8) chunk = D / 8 - 1;            // filler slots of the d = 96 image: any valid address
-      rowk[k] = row; colk[k] = 8 * chunk;
-      goff[k] = (int)(row * g_stride) + 8 * chunk;
+      int row, col;
+      where(k, w, lane, row, col);
+      boff[k] = 2u * (uint32_t)(row * g_stride + col);
     }
   }
-  // g: start of the (batch, head) slab; row0: first row of the tile; limit: rows of the slab (>= 1).  Rows past the
-  // slab re-read its last row (finite data; their scores are masked / their probabilities are exactly 0).
-  __device__ __forceinline__ void piece(int k, const bf16_t* g, int64_t g_stride, int64_t row0, int64_t limit, uint32_t tile /* LDS byte address */, int w) const {
-    const bf16_t* base = g + row0 * g_stride;           // wave-uniform
-    const int left = (int)(limit - row0 < (1 << 29) ? limit - row0 : (1 << 29));
-    const bf16_t* src = base + (left >= 64 || rowk[k] < left ? goff[k] : (int)((left - 1) * g_stride) + colk[k]);
-    // Inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read it cannot prove disjoint
-    // (s_waitcnt vmcnt(0) right behind the DMA), which exposes the whole load latency.  The asm form is invisible
-    // to that bookkeeping; the kernel waits for its DMA itself (dma_wait() ahead of the barrier that publishes the
-    // tile).  M0 = LDS base of the piece, saved / restored around the instruction (guide 5.7, glds16 recipe).
+  // LDS-DMA through inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read it cannot prove
+  // disjoint (s_waitcnt vmcnt(0) right behind the DMA), which exposes the whole load latency.  The asm form is
+  // invisible to that bookkeeping; the kernel waits for its DMA itself (dma_wait() ahead of the barrier that
+  // publishes the tile).  M0 = LDS base of the piece, saved / restored around the instruction (guide 5.7, glds16).
+  //
+  // Hot-loop form, INTERIOR tiles only (all 64 rows inside the slab): wave-uniform 64-bit base in SGPRs + the lane's
+  // 32-bit byte offset: no VALU address arithmetic at all inside the MFMA gaps.
+  __device__ __forceinline__ void piece_fast(int k, const bf16_t* base /* g + row0 * stride, wave-uniform */, uint32_t tile, int w) const {
     const uint32_t dst_u = __builtin_amdgcn_readfirstlane(tile + 1024u * (uint32_t)(w + NW * k));
     uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst_u) : "memory");
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(boff[k]), "s"(base), "s"(dst_u) : "memory");
   }
-  __device__ __forceinline__ void issue(const bf16_t* g, int64_t g_stride, int64_t row0, int64_t limit, uint32_t tile /* LDS byte address */, int w) const {
+  // General form (prologue / tail): rows past the slab re-read its last row (finite data; their scores are masked /
+  // their probabilities are exactly 0).  g: start of the (batch, head) slab; limit: rows of the slab (>= 1, row0 < limit).
+  __device__ __forceinline__ void issue(const bf16_t* g, int64_t g_stride, int64_t row0, int64_t limit, uint32_t tile, int w, int lane) const {
+    const int left = (int)(limit - row0 < (1 << 29) ? limit - row0 : (1 << 29));
 #pragma unroll
-    for (int k = 0; k < PER; ++k) piece(k, g, g_stride, row0, limit, tile, w);
+    for (int k = 0; k < PER; ++k) {
+      int row, col;
+      where(k, w, lane, row, col);
+      const bf16_t* src = g + (row0 + (row < left ? row : left - 1)) * g_stride + col;
+      const uint32_t dst_u = __builtin_amdgcn_readfirstlane(tile + 1024u * (uint32_t)(w + NW * k));
+      uint32_t keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst_u) : "memory");
+    }
   }
 };
 
@@ -105,17 +119,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   using G = Img<D>;
   constexpr int KT = 64, DB = D / 32, NQ = D / 16, NP = 2 * DB, NM = NQ + 1 + NP, RP = G::RP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];      // K ring [NB][TILE], then V ring [NB][TILE]
-  unsigned char (*ks)[G::TILE] = reinterpret_cast<unsigned char (*)[G::TILE]>(smem_dyn);
-  unsigned char (*vs)[G::TILE] = reinterpret_cast<unsigned char (*)[G::TILE]>(smem_dyn + NB * G::TILE);
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
-  const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
+  // 1-D grid of (query block, (batch, head) pair) items.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 says
+  // which ids share an XCD, hence an L2): the query blocks of one pair are mapped to ids with equal id % 8 and
+  // consecutive id / 8, so that a pair's K / V is fetched into ONE L2, once, instead of into up to nq of them
+  // (speed only, never correctness: guide T1).
+  const uint32_t nq = p.grid_q, npairs = p.grid_pairs, id = blockIdx.x;
+  uint32_t qb, pair;
+  if (nq > 1 && npairs % 8 == 0) { const uint32_t slot = id >> 3; pair = (slot / nq) * 8 + (id & 7); qb = slot % nq; }
+  else { qb = id % nq; pair = id / nq; }
+  const int64_t b = pair / p.h, hd = pair % p.h;
   int64_t lq_, lk_, qbase, kbase, lse_base;
   seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
-  if ((int64_t)blockIdx.x * (NW * 32) >= lq_) return;            // varlen: tile past this sequence (block-uniform)
-  const int64_t q_row = (int64_t)blockIdx.x * (NW * 32) + w * 32 + r;
+  if ((int64_t)qb * (NW * 32) >= lq_) return;                    // varlen: tile past this sequence (block-uniform)
+  const int64_t q_row = (int64_t)qb * (NW * 32) + w * 32 + r;
   const bool q_ok = q_row < lq_;
   // a wave whose 32 queries all lie past the sequence (short packed sequences) only helps staging K/V
-  const bool wave_live = (int64_t)blockIdx.x * (NW * 32) + w * 32 < lq_;
+  const bool wave_live = (int64_t)qb * (NW * 32) + w * 32 < lq_;
   int64_t kvlen64 = lk_;
   if (p.kv_len) { kvlen64 = p.kv_len[b]; if (kvlen64 > lk_) kvlen64 = lk_; if (kvlen64 < 0) kvlen64 = 0; }
   const int kvlen = (int)(kvlen64 < (1 << 30) ? kvlen64 : (1 << 30));
@@ -147,32 +167,45 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   const int nunits = (kvlen + 31) >> 5;       // 32-key score blocks that hold at least one valid key
   const int ntiles = (nunits + 1) >> 1;
   const int last_valid = kvlen - 32 * (nunits - 1);   // valid keys of the last block (1..32)
-  // lane constants of the LDS operand reads (byte offsets inside a tile image)
-  int koff[NQ];                                         // K A-operand, contraction step s: row r, chunk 2s + h
+  // lane constants of the LDS operand reads: ABSOLUTE LDS byte addresses of the lane's spot in tile buffer 0 of the K
+  // ring; everything else (buffer, V ring, row block, contraction step) is an immediate offset in the hot loop
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem_dyn;
+  uint32_t koff[NQ];                                    // K A-operand, contraction step s: row r, chunk 2s + h
 #pragma unroll
-  for (int s = 0; s < NQ; ++s) koff[s] = r * RP + (((2 * s + h) ^ G::fk(r)) << 4);
-  int voff[DB];                                         // V^T A-operand, d-block db: row 4*(lane>>5) + qq, chunk 4 db + 2 g1 + (pp >> 1)
+  for (int s = 0; s < NQ; ++s) koff[s] = lds0 + r * RP + (((2 * s + h) ^ G::fk(r)) << 4);
+  uint32_t voff[DB];                                    // V^T A-operand, d-block db: row 4*(lane>>5) + qq, chunk 4 db + 2 g1 + (pp >> 1)
   {
     const int qq = (lane & 15) >> 2, pp = lane & 3, g1 = (lane >> 4) & 1, row = 4 * (lane >> 5) + qq;
 #pragma unroll
-    for (int db = 0; db < DB; ++db) voff[db] = row * RP + (((4 * db + 2 * g1 + (pp >> 1)) ^ G::fv(row)) << 4) + 8 * (pp & 1);
+    for (int db = 0; db < DB; ++db) voff[db] = lds0 + row * RP + (((4 * db + 2 * g1 + (pp >> 1)) ^ G::fv(row)) << 4) + 8 * (pp & 1);
   }
-  auto kfrag = [&](const unsigned char* tile, int row0, int s) {
-    return *reinterpret_cast<const bf16x8*>(tile + row0 * RP + koff[s]);
+  typedef __attribute__((address_space(3))) const bf16x8* lds_b128_t;
+  typedef __attribute__((address_space(3))) bf16x4* lds_b64_t;
+  // off: byte offset of the tile buffer + row block from the start of the K ring (runtime in the generic step,
+  // a compile-time constant in the hot loop, where it folds into the ds_read offset field)
+  auto kfrag = [&](uint32_t off, int s) { return *(lds_b128_t)(size_t)(koff[s] + off); };
+  auto vfrag = [&](uint32_t off, int j, bf16x4& lo, bf16x4& hi) {   // PV MFMA j: k-step j / DB, d-block j % DB
+    const uint32_t a = voff[j % DB] + off + (uint32_t)(16 * (j / DB) * RP);
+    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(size_t)a);
+    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(size_t)(a + 8 * RP));
   };
-  auto vfrag = [&](const unsigned char* tile, int row0, int j, bf16x4& lo, bf16x4& hi) {   // PV MFMA j: k-step j / DB, d-block j % DB
-    const unsigned char* a = tile + (row0 + 16 * (j / DB)) * RP + voff[j % DB];
-    lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, a));
-    hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, a + 8 * RP));
-  };
+  auto k_at = [&](int buf, int row0) { return (uint32_t)(buf * G::TILE + row0 * RP); };            // K ring
+  auto v_at = [&](int buf, int row0) { return (uint32_t)((NB + buf) * G::TILE + row0 * RP); };     // V ring (behind the K ring)
 
-  // probabilities of scores 2j, 2j+1 of block u: exp2, partial row sum, (dropout), bf16 pair
-  auto sm_pair = [&](const f32x16& sc, bf16x8 (&pc)[2], int u, int j, float& rs0, float& rs1) {
+  // probabilities of scores 2j, 2j+1 of block u: exp2, (dropout), bf16 pair.  The row-sum adds run ONE PAIR BEHIND
+  // (pe0 / pe1 hold the previous pair's exponentials): a v_add that consumes a v_exp issued two instructions earlier
+  // stalls on the transcendental pipe's latency; consuming the previous gap's pair does not.
+  auto sm_pair = [&](const f32x16& sc, bf16x8 (&pc)[2], int u, int j, float& rs0, float& rs1, float& pe0, float& pe1) {
     const int i = 2 * j;
     const float e0 = fast_exp2(sc[i]);                               // masked: exp2(-inf) = 0
     const float e1 = fast_exp2(sc[i + 1]);
-    rs0 += e0;                                                       // the normaliser uses the un-dropped probabilities
-    rs1 += e1;
+#ifndef GMLM_NO_PIPE_ADD
+    if (j == 1) { rs0 = pe0; rs1 = pe1; }                            // the normaliser uses the un-dropped probabilities
+    else if (j > 1) { rs0 += pe0; rs1 += pe1; }
+    pe0 = e0; pe1 = e1;
+#else
+    rs0 += e0; rs1 += e1;
+#endif
     float d0 = e0, d1 = e1;
     if (DROP) {
       const uint32_t wd = drop_word(seed32, qmix, (uint32_t)((32 * u + acc_row(i, h)) >> 1));
@@ -183,26 +216,26 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     pc[i >> 3][(i & 7) + 1] = (__bf16)d1;
   };
   auto softmax_block = [&](const f32x16& sc, bf16x8 (&pc)[2], int u) {
-    float rs0 = 0.f, rs1 = 0.f;
+    float rs0 = 0.f, rs1 = 0.f, pe0 = 0.f, pe1 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) sm_pair(sc, pc, u, j, rs0, rs1);
-    l += rs0 + rs1;
+    for (int j = 0; j < 8; ++j) sm_pair(sc, pc, u, j, rs0, rs1, pe0, pe1);
+    l += (rs0 + pe0) + (rs1 + pe1);
   };
   // S'^T(block) = K(rows row0..row0+31) Q'^T - m: the max column first, then the D/16 real contraction steps
-  auto qk_unit = [&](const unsigned char* tile, int row0, f32x16& s) {
+  auto qk_unit = [&](uint32_t koffs, f32x16& s) {
     f32x16 z;
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
     s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qx, z, 0, 0, 0);
 #pragma unroll
-    for (int t = 0; t < NQ; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(tile, row0, t), qf.v[t], s, 0, 0, 0);
+    for (int t = 0; t < NQ; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(koffs, t), qf.v[t], s, 0, 0, 0);
   };
   // O^T[db] += V^T(tile rows row0..row0+31) * P^T, P packed to bf16 in accumulator order (k-step s = regs 8s..8s+7)
-  auto pv_unit = [&](const unsigned char* tile, int row0, const bf16x8 (&pk)[2]) {
+  auto pv_unit = [&](uint32_t voffs, const bf16x8 (&pk)[2]) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       bf16x4 lo, hi;
-      vfrag(tile, row0, j, lo, hi);
+      vfrag(voffs, j, lo, hi);
       bf16x8 a;
 #pragma unroll
       for (int t = 0; t < 4; ++t) { a[t] = lo[t]; a[4 + t] = hi[t]; }
@@ -247,28 +280,29 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   //  sc: scores of block u (log2 domain, reference max subtracted)   pc: packed probabilities of block u (output)
   //  sn: receives the scores of block u+1                              pp: packed probabilities of block u-1
   auto step = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u, bool has_pv, bool has_qk,
-                  const unsigned char* vprev, int vrow0, const unsigned char* knext, int krow0) {
+                  uint32_t voffs, uint32_t koffs) {
     bool rare;
     const float alpha = check(sc, u, rare);
-    if (has_pv) pv_unit(vprev, vrow0, pp);
-    if (has_qk) qk_unit(knext, krow0, sn);
+    if (has_pv) pv_unit(voffs, pp);
+    if (has_qk) qk_unit(koffs, sn);
     softmax_block(sc, pc, u);
     if (rare) scale_o(alpha);
   };
   // ---- steady-state step: PV(u-1) and QK(u+1) on the matrix pipe under the softmax of block u ---------------
   auto step_full = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u,
-                       const unsigned char* vprev, int vrow0, const unsigned char* knext, int krow0, auto&& gap_hook) {
-    // operand reads of the first MFMAs go out before the check: its ~15 VALU instructions cover their latency
+                       auto voffs_c, auto koffs_c, auto&& gap_hook) {
+    constexpr uint32_t voffs = decltype(voffs_c)::value, koffs = decltype(koffs_c)::value;   // compile-time: ds_read offset fields
+    // operand reads of the first MFMAs go out before the check: its ~12 VALU instructions cover their latency
     bf16x8 ka[NQ];
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) ka[s] = kfrag(knext, krow0, s);
+    for (int s = 0; s < NQ; ++s) ka[s] = kfrag(koffs, s);
     bf16x4 vlo[NP], vhi[NP];
     constexpr int LA = 3;                               // PV operand reads run LA gaps ahead of their MFMA
     bool rare;
     const float alpha = check(sc, u, rare);
     // hand-placed: one MFMA per gap, the operand reads of a later MFMA, one probability pair;
     // sched_barrier(0) keeps every gap's instructions inside the gap
-    float rs0 = 0.f, rs1 = 0.f;
+    float rs0 = 0.f, rs1 = 0.f, pe0 = 0.f, pe1 = 0.f;
     int pair = 0;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -289,16 +323,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
       }
       {
         const int j = g + LA - NQ - 1;                  // PV MFMA whose operands are fetched in this gap
-        if (j >= 0 && j < NP) vfrag(vprev, vrow0, j, vlo[j], vhi[j]);
+        if (j >= 0 && j < NP) vfrag(voffs, j, vlo[j], vhi[j]);
       }
       gap_hook(g);
-      if (pair < 8 && (NM <= 9 || (g % 3) != 2)) { sm_pair(sc, pc, u, pair, rs0, rs1); ++pair; }
+      if (pair < 8 && (NM <= 9 || (g % 3) != 2)) { sm_pair(sc, pc, u, pair, rs0, rs1, pe0, pe1); ++pair; }
       __builtin_amdgcn_sched_barrier(0);
     }
     // pin the probabilities inside this basic block (their consumers are in later blocks: without a use here the
     // compiler sinks the whole softmax below the MFMAs, past the branch that follows)
-    asm volatile("" : "+v"(pc[0]), "+v"(pc[1]), "+v"(rs0), "+v"(rs1));
-    l += rs0 + rs1;
+    asm volatile("" : "+v"(pc[0]), "+v"(pc[1]), "+v"(rs0), "+v"(rs1), "+v"(pe0), "+v"(pe1));
+    l += (rs0 + pe0) + (rs1 + pe1);
     if (rare) scale_o(alpha);
   };
 
@@ -309,8 +343,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
 #else
 #define STAMP(x)
 #endif
-  // LDS byte addresses of the tile buffers (the DMA destination goes through M0)
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem_dyn;
   auto ks_a = [&](int t) { return lds0 + (uint32_t)((t % NB) * G::TILE); };                 // LDS address of K tile t's buffer
   auto vs_a = [&](int t) { return lds0 + (uint32_t)((NB + t % NB) * G::TILE); };
   DmaPlan<D, NW, false> kd;
@@ -319,84 +351,93 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   vd.init(p.v_stride, w, lane);
   f32x16 sa, sb;
   bf16x8 pa[2], pb[2];
+  static_assert(NB == 2, "the parity-unrolled main loop assumes two buffers per operand");
   constexpr int PK = DmaPlan<D, NW, false>::PER;       // DMA pieces per tile and wave
-  constexpr int AHEAD = NB - 1;                         // K tile i + AHEAD and V tile i + AHEAD - 1 are requested in iteration i
   if (ntiles > 0) {
-    // prologue: K tiles 0..AHEAD, V tiles 0..AHEAD-1 by DMA; QK(0); step 0
-    kd.issue(kg, p.k_stride, 0, lk_, ks_a(0), w);
-    vd.issue(vg, p.v_stride, 0, lk_, vs_a(0), w);
-    if (ntiles > 1) kd.issue(kg, p.k_stride, KT, lk_, ks_a(1), w);
-    if (NB == 3) {
-      if (ntiles > 1) vd.issue(vg, p.v_stride, KT, lk_, vs_a(1), w);
-      if (ntiles > 2) kd.issue(kg, p.k_stride, 2 * KT, lk_, ks_a(2), w);
-    }
-    if (NB == 3 && ntiles > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PK) : "memory");   // K0, V0, K1 have landed; V1, K2 stay in flight
-    else dma_wait();
+    // Invariant at the top of iteration i (steps 2i-1 and 2i; reads K tile i and V tile i-1): both are in LDS and
+    // published; K tile i+1 and V tile i have not been requested.  The iteration requests them (K tile i+1 into the
+    // buffer K tile i-1 left, V tile i into the buffer V tile i-2 left, both last read before the previous barrier),
+    // waits for its own DMA and closes with the ONE barrier per 64 keys.
+    // prologue: K tile 0, V tile 0, K tile 1; QK(0); step 0
+    kd.issue(kg, p.k_stride, 0, lk_, ks_a(0), w, lane);
+    vd.issue(vg, p.v_stride, 0, lk_, vs_a(0), w, lane);
+    if (ntiles > 1) kd.issue(kg, p.k_stride, KT, lk_, ks_a(1), w, lane);
+    dma_wait();
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < NQ; ++s) asm volatile("" :: "v"(qf.v[s]));   // Q has landed too: no vmcnt wait for it inside the loop
     if (wave_live) {
-      qk_unit(ks[0], 0, sa);
-      step(sa, pa, sb, pb, 0, false, nunits > 1, vs[0], 0, ks[0], 32);
+      qk_unit(k_at(0, 0), sa);
+      step(sa, pa, sb, pb, 0, false, nunits > 1, v_at(0, 0), k_at(0, 32));
     }
     __syncthreads();                                    // every wave is done with K tile 0 before iteration 1 refills its buffer
-    // iteration i: steps 2i-1 and 2i; reads K tile i and V tile i-1; its DMA (riding in the MFMA gaps of its first
-    // step) requests K tile i+AHEAD into the buffer K tile i-1 left and V tile i+AHEAD-1 into the buffer V tile i-2
-    // left, both last read before the previous barrier: ONE barrier per 64 keys.  With three buffers the wait ahead
-    // of that barrier covers only the PREVIOUS iteration's pieces: a request has two iterations to land.
+    // ---- main loop: both steps have a block ahead and a block behind, and the requested tiles are INTERIOR (all 64
+    // rows inside the slab), so the DMA pieces need no per-lane clamping.  Unrolled by the buffer parity: every LDS
+    // operand address is lane constant + immediate.
     int i = 1;
-    for (; 2 * i + 1 < nunits; ++i) {                   // both steps have a block ahead and a block behind
+    auto hot = [&](int ii) { return 2 * ii + 1 < nunits && (int64_t)(ii + 2) * KT <= lk_; };
+    auto iteration = [&](auto par_c, int ii) {
+      constexpr int PAR = decltype(par_c)::value;       // = ii & 1: K tile ii lives in K buffer PAR, V tile ii-1 in V buffer PAR ^ 1
       STAMP(t0_);
-      const int tk = i + AHEAD, tv = i + AHEAD - 1;     // tiles requested in this iteration
-      const bool more_k = tk < ntiles, more_v = tv < ntiles;
-      const unsigned char* kc = ks[i % NB];
-      const unsigned char* vp = vs[(i - 1) % NB];
-      auto dma_hook = [&](int g) {                      // pieces spread over gaps 1 .. NM-1, K first
+      const T* kbase = kg + (int64_t)(ii + 1) * KT * p.k_stride;      // wave-uniform: SGPR pair
+      const T* vbase = vg + (int64_t)ii * KT * p.v_stride;
+      auto dma_hook = [&](int g) {                      // this iteration's pieces ride in gaps 1 .. NM-1 of its first step, K first
         constexpr int C = (2 * PK + NM - 2) / (NM - 1);
         if (g < 1) return;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
           const int q = (g - 1) * C + c;
-          if (q < PK) { if (more_k) kd.piece(q, kg, p.k_stride, (int64_t)tk * KT, lk_, ks_a(tk), w); }
-          else if (q < 2 * PK) { if (more_v) vd.piece(q - PK, vg, p.v_stride, (int64_t)tv * KT, lk_, vs_a(tv), w); }
+          if (q < PK) kd.piece_fast(q, kbase, lds0 + (uint32_t)((PAR ^ 1) * G::TILE), w);
+          else if (q < 2 * PK) vd.piece_fast(q - PK, vbase, lds0 + (uint32_t)((NB + PAR) * G::TILE), w);
         }
       };
+      using VO0 = std::integral_constant<uint32_t, (uint32_t)((NB + (PAR ^ 1)) * G::TILE)>;
+      using VO1 = std::integral_constant<uint32_t, (uint32_t)((NB + (PAR ^ 1)) * G::TILE + 32 * RP)>;
+      using KO0 = std::integral_constant<uint32_t, (uint32_t)(PAR * G::TILE)>;
+      using KO1 = std::integral_constant<uint32_t, (uint32_t)(PAR * G::TILE + 32 * RP)>;
       STAMP(t1_);
       if (wave_live) {
-        step_full(sb, pb, sa, pa, 2 * i - 1, vp, 0, kc, 0, dma_hook);
-        step_full(sa, pa, sb, pb, 2 * i, vp, 32, kc, 32, [](int) {});
+        step_full(sb, pb, sa, pa, 2 * ii - 1, VO0{}, KO0{}, dma_hook);
+        step_full(sa, pa, sb, pb, 2 * ii, VO1{}, KO1{}, [](int) {});
       } else {
 #pragma unroll
         for (int g = 0; g < NM; ++g) dma_hook(g);
       }
       STAMP(t2_);
-      if (NB == 3 && more_k) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PK) : "memory");   // more_k implies more_v: exactly 2 PK pieces of this iteration may stay in flight
-      else dma_wait();
+      dma_wait();
       STAMP(t3_);
       __syncthreads();
       STAMP(t4_);
 #ifdef GMLM_ATTN_STAMP
       t_load += t1_ - t0_; t_steps += t2_ - t1_; t_stage += t3_ - t2_; t_bar += t4_ - t3_;
 #endif
+    };
+    for (; hot(i + 1); i += 2) {                        // i is odd at the top; hot(i + 1) implies hot(i)
+      iteration(std::integral_constant<int, 1>{}, i);
+      iteration(std::integral_constant<int, 0>{}, i + 1);
     }
-    for (; 2 * i - 1 < nunits; ++i) {                   // tail: the last one or two blocks
-      const int tv = i + AHEAD - 1;
-      if (tv < ntiles && NB == 2) vd.issue(vg, p.v_stride, (int64_t)tv * KT, lk_, vs_a(tv), w);   // (with three buffers the last V tile is already on its way)
-      const unsigned char* kc = ks[i % NB];
-      const unsigned char* vp = vs[(i - 1) % NB];
+    if (hot(i)) {                                       // one more interior iteration (odd i)
+      iteration(std::integral_constant<int, 1>{}, i);
+      ++i;
+    }
+    // ---- tail: the last blocks and the (possibly partial) last tile: generic steps, clamping DMA
+    for (; 2 * i - 1 < nunits; ++i) {
+      if (i + 1 < ntiles) kd.issue(kg, p.k_stride, (int64_t)(i + 1) * KT, lk_, ks_a(i + 1), w, lane);
+      if (i < ntiles) vd.issue(vg, p.v_stride, (int64_t)i * KT, lk_, vs_a(i), w, lane);
+      const int kb = i % NB, vb = (i - 1) % NB;
       if (wave_live) {
-        step(sb, pb, sa, pa, 2 * i - 1, true, 2 * i < nunits, vp, 0, kc, 0);
-        if (2 * i < nunits) step(sa, pa, sb, pb, 2 * i, true, false, vp, 32, kc, 32);
-        else pv_unit(vp, 32, pb);                                       // nunits even: last block retired here
+        step(sb, pb, sa, pa, 2 * i - 1, true, 2 * i < nunits, v_at(vb, 0), k_at(kb, 0));
+        if (2 * i < nunits) step(sa, pa, sb, pb, 2 * i, true, 2 * i + 1 < nunits, v_at(vb, 32), k_at(kb, 32));
+        else pv_unit(v_at(vb, 32), pb);                                 // nunits even: last block retired here
       }
       dma_wait();
       __syncthreads();
     }
-    if ((nunits & 1) && wave_live) pv_unit(vs[(ntiles - 1) % NB], 0, pa);   // nunits odd: last block = first half of the last V tile
+    if ((nunits & 1) && wave_live) pv_unit(v_at((ntiles - 1) % NB, 0), pa);   // nunits odd: last block = first half of the last V tile
   }
 #ifdef GMLM_ATTN_STAMP
   if (lane == 0 && p.delta) {     // diagnostic build: p.delta = uint64 [waves][6]
-    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.delta) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * NW + w) * 6;
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.delta) + ((size_t)blockIdx.x * NW + w) * 6;
     dbg[0] = t_load; dbg[1] = t_steps; dbg[2] = t_stage; dbg[3] = t_bar; dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; dbg[5] = (uint64_t)nunits;
   }
 #endif
@@ -411,7 +452,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
 }
 
 template <int D, int NW, int NB>
-static int launch_pipe(dim3 grid, hipStream_t st, const AttnParams& p) {
+static int launch_pipe(dim3 grid2, hipStream_t st, const AttnParams& p0) {
+  AttnParams p = p0;
+  p.grid_q = grid2.x; p.grid_pairs = grid2.y;
+  const dim3 grid(grid2.x * grid2.y);
   constexpr int kLds = 2 * NB * Img<D>::TILE;
   static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs the attribute once per instantiation
   if (!attr_set) {
@@ -424,13 +468,13 @@ static int launch_pipe(dim3 grid, hipStream_t st, const AttnParams& p) {
   return GMLM_OK;
 }
 
-// bf16 forward entry used by gmlm_attention_fwd (attn_kernels.hip); nw = waves per workgroup (4 or 8).  Only the
-// configurations that are dispatched are instantiated (d = 96, two LDS buffers per operand); the kernel template also
-// covers d = 64 and a 3-deep ring, both measured and not adopted.
+// bf16 forward entry used by gmlm_attention_fwd (attn_kernels.hip); nw = waves per workgroup.  Only the
+// configurations that are dispatched are instantiated.
 int attn_fwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t bh, hipStream_t st) {
   dim3 grid((unsigned)cdiv(rows_q, nw * 32), (unsigned)bh);
   if (d == 96 && nw == 8) return launch_pipe<96, 8, 2>(grid, st, p);
   if (d == 96 && nw == 4) return launch_pipe<96, 4, 2>(grid, st, p);
+  if (d == 64 && nw == 4) return launch_pipe<64, 4, 2>(grid, st, p);
   set_error("attention_fwd: no pipelined kernel for d = %d with %d waves", d, nw);
   return GMLM_EINVAL;
 }

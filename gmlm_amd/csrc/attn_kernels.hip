@@ -482,7 +482,6 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
   };
   uint4 ra[PER], rc[PER];
   load2(kg, p.k_stride, vg, p.v_stride, lk_, ra, rc);
-  store2(ra, rc, lk_);
   const float sl2 = p.scale * kLog2e;
   const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
   const int kvl = (int)kvlen;                               // <= 128: 32-bit index arithmetic below
@@ -490,20 +489,22 @@ __global__ __launch_bounds__(256) void attn_bwd_short_kernel(AttnParams p) {
   const int64_t q_row = w * 32 + r;
   const bool q_ok = q_row < lq_;
   const bool q_wave = w * 32 < lq_;
-  RowFrag<T, D> qf, dof;
+  RowFrag<T, D> qf, dof, of;
   float lse2 = 0.f, dl = 0.f;
-  if (q_wave) {
-    const int64_t qr = q_ok ? q_row : 0;
+  if (q_wave) {                                             // this wave's Q / dO / O rows: requested BEFORE the K / V tile is
+    const int64_t qr = q_ok ? q_row : 0;                    // written to LDS (one memory round trip for both, not two)
     qf.load(qg + qr * p.q_stride, q_ok, h);
     dof.load(dog + qr * do_stride, q_ok, h);
-    RowFrag<T, D> of;
     of.load(og + qr * do_stride, q_ok, h);
+    lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : INFINITY;   // +inf: a row past the sequence gets probability 0
+  }
+  store2(ra, rc, lk_);
+  if (q_wave) {
 #pragma unroll
     for (int s = 0; s < D / 16; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) dl = fmaf((float)dof.v[s][j], (float)of.v[s][j], dl);
     dl = xhalf_sum(dl);
-    lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : INFINITY;   // +inf: a row past the sequence gets probability 0
     if (h == 0) { lse_s[q_row] = lse2; dl_s[q_row] = q_ok ? dl : 0.f; }
   }
   __syncthreads();
@@ -607,7 +608,7 @@ static int attn_check(const char* who, int64_t b, int64_t h, int64_t lq, int64_t
   GMLM_REQUIRE(b >= 0 && h > 0 && lq >= 0 && lk >= 0, "%s: bad sizes", who);
   GMLM_REQUIRE(d == 64 || d == 96, "%s: head dim %ld not supported (64 or 96)", who, (long)d);
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "%s: unsupported dtype", who);
-  GMLM_REQUIRE(b * h <= 65535, "%s: batch*heads %ld > 65535", who, (long)(b * h));
+  GMLM_REQUIRE(b * h <= 65535, "%s: batch*heads %ld > 65535", who, (long)(b * h));   // grid.y of the two-dimensional launches
   return GMLM_OK;
 }
 static int stride_check(const char* who, const void* ptr, int64_t stride, int64_t min_stride, int dtype) {
@@ -680,10 +681,13 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
 #ifdef GMLM_ATTN_STAMP
   p.delta = static_cast<float*>(g_stamp_buffer);
 #endif
-  if (dtype == GMLM_BF16 && d == 96) {
-    // CrossAttention geometry: software-pipelined LDS-DMA kernel (attn_fwd_pipe.hip): +23-26 % at N = 5k-20k.  At d = 64
-    // (BERT, sequences <= 512 tokens) the two kernels measure the same and the lighter one below keeps 3 waves per SIMD.
-    rc = attn_fwd_pipe_launch(p, 96, pick_waves(rows_q, b * h) == 8 ? 8 : 4, rows_q, b * h, st);
+  if (dtype == GMLM_BF16 && (d == 96 || rows_q > 128)) {
+    // software-pipelined LDS-DMA kernel (attn_fwd_pipe.hip): CrossAttention geometry (d = 96: +40-45 % at N = 5k-20k
+    // against attn_fwd_kernel) and BERT geometry beyond 128 tokens (d = 64: +8 % at L = 512, +15 % at L = 2048).
+    // Sequences of <= 128 tokens (one query block per sequence: what the reference's tokeniser produces,
+    // main.py:340) stay on the lighter kernel below, which keeps 3 waves per SIMD and is 5-9 % faster there.
+    const int nw = d == 96 ? (pick_waves(rows_q, b * h) == 8 ? 8 : 4) : 4;
+    rc = attn_fwd_pipe_launch(p, (int)d, nw, rows_q, b * h, st);
     if (rc != GMLM_OK) return rc;
     GMLM_LAUNCH_CHECK();
     return GMLM_OK;

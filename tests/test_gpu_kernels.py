@@ -405,11 +405,17 @@ def test_spmm_power_law_long_segments(dev):
     assert torch.equal(h, RGCNAggregate.apply(xg, csr))          # deterministic
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 5e-2)])
 def test_attention_online_softmax_rescale_branch(dev, dt, tol):
     """The kernel skips the running-max rescale while the max grows by < 2^6 and rescales otherwise.  Random
     data almost never takes the rescale branch after the first tile, so force it: a few keys far down the
-    sequence score 40+ above everything before them for some queries (and not for others)."""
+    sequence score 40+ above everything before them for some queries (and not for others).
+
+    bf16 tolerance 5e-2: the forced scores reach 50-100 (natural units).  The pipelined forward pre-multiplies q by
+    scale * log2(e) and rounds once more to bf16 (relative 2^-9 per element), i.e. a score error of about
+    |s| * 2^-9 / sqrt(d) * sqrt(d) ~ 0.1-0.2 at |s| = 100 in the worst element -> a few % on a probability that is
+    not saturated.  (The reference's own GPU arithmetic is fp16 autocast, main.py:543: its scores carry an absolute
+    error of 2^-4 at that magnitude.)  At |s| <~ 15 - trained attention logits - the effect is < 0.5 %."""
     from gmlm_amd.ops import attention
     b, h, l, d = 1, 2, 400, 64
     g = torch.Generator().manual_seed(17)

@@ -1,9 +1,15 @@
-"""Per-step kernel breakdown from a rocprofv3 --kernel-trace rocpd database of `bench.py --no-micro --no-cpu-baseline`.
-usage: python tools/step_breakdown.py <results.db> [n_timed_steps]"""
-import sqlite3, collections, sys
-db = sqlite3.connect(sys.argv[1])
+"""Per-step kernel breakdown from a rocprofv3 --kernel-trace run of `bench.py --no-micro --no-cpu-baseline --no-fp32-leg`
+(CSV kernel trace, or the rocpd database of older runs).
+usage: python tools/step_breakdown.py <kernel_trace.csv | results.db> [n_timed_steps] [top]"""
+import collections, csv, sqlite3, sys
+path = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-rows = list(db.execute("select name, start, end, vgpr_count, lds_size from kernels order by start"))
+if path.endswith(".csv"):
+    rows = [(r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("VGPR_Count", "?"), r.get("LDS_Block_Size", "?"))
+            for r in csv.DictReader(open(path))]
+    rows.sort(key=lambda r: r[1])
+else:
+    rows = list(sqlite3.connect(path).execute("select name, start, end, vgpr_count, lds_size from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if 'softmask_fwd_kernel' in r[0]]
 sel = rows[idx[-steps]:]
 t0, t1 = sel[0][1], max(r[2] for r in sel)

@@ -40,7 +40,9 @@ int main(int argc, char** argv) {
   const Case cases[] = {{"mha_L512", 32, 12, 512, 64, true, 0.f}, {"mha_L128", 256, 12, 128, 64, true, 0.f},
                         {"xattn_N5201", 1, 8, 5201, 96, false, 0.f}, {"xattn_N20804", 1, 8, 20804, 96, false, 0.f},
                         {"mha_L512_drop", 32, 12, 512, 64, true, 0.1f}, {"mha_L77_odd", 64, 12, 77, 64, true, 0.f},
-                        {"xattn_N999", 1, 8, 999, 96, false, 0.f}};
+                        {"xattn_N999", 1, 8, 999, 96, false, 0.f},
+                        {"mha_L512_b8", 8, 12, 512, 64, true, 0.f}, {"mha_L512_b128", 128, 12, 512, 64, true, 0.f},
+                        {"mha_L512_full", 32, 12, 512, 64, false, 0.f}, {"mha_L2048", 8, 12, 2048, 64, false, 0.f}};
   std::mt19937 rng(1234);
   std::normal_distribution<float> nd(0.f, 1.f);
   for (const Case& c : cases) {
@@ -138,6 +140,39 @@ int main(int argc, char** argv) {
     (void)hipFree(q); (void)hipFree(k); (void)hipFree(v); (void)hipFree(o); (void)hipFree(go); (void)hipFree(dq); (void)hipFree(dk); (void)hipFree(dv);
     (void)hipFree(qf); (void)hipFree(kf); (void)hipFree(vf); (void)hipFree(of); (void)hipFree(gof); (void)hipFree(dqf); (void)hipFree(dkf); (void)hipFree(dvf);
     (void)hipFree(lse); (void)hipFree(lsef); (void)hipFree(ws); if (len) (void)hipFree(len);
+  }
+  if (!only || strstr("packed_mix", only)) {
+    // the in-step BERT batch: 1,257 sequences of 16..128 tokens packed back to back (cu_seqlens), fused QKV rows, h = 12, d = 64, p = 0.1
+    const int64_t nseq = 1257, h = 12, d = 64, hd = h * d;
+    std::vector<int32_t> cu(nseq + 1, 0);
+    double pairs = 0;
+    for (int64_t i = 0; i < nseq; ++i) { const int len = 16 + (int)(rng() % 113); cu[i + 1] = cu[i] + len; pairs += (double)len * len; }
+    const int64_t T = cu[nseq];
+    std::vector<uint16_t> hqkv(T * 3 * hd), hgo(T * hd);
+    for (auto& x : hqkv) x = f2bf(nd(rng) * 0.5f);
+    for (auto& x : hgo) x = f2bf(nd(rng));
+    uint16_t *qkv, *o, *go, *dqkv; float* lse; int32_t* dcu; void* ws;
+    CK(hipMalloc(&qkv, T * 3 * hd * 2)); CK(hipMalloc(&dqkv, T * 3 * hd * 2)); CK(hipMalloc(&o, T * hd * 2)); CK(hipMalloc(&go, T * hd * 2));
+    CK(hipMalloc(&lse, T * h * 4)); CK(hipMalloc(&dcu, (nseq + 1) * 4));
+    const size_t wsb = gmlm_attention_bwd_workspace_bytes(1, h, T, T, d);
+    CK(hipMalloc(&ws, wsb));
+    CK(hipMemcpy(qkv, hqkv.data(), T * 3 * hd * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(go, hgo.data(), T * hd * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dcu, cu.data(), (nseq + 1) * 4, hipMemcpyHostToDevice));
+    const float scale = 0.125f;
+    auto fwd = [&]() { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, o, lse, GMLM_BF16, dcu, 128, nullptr)); };
+    auto bwd = [&]() { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77,
+                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr)); };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float ms;
+    for (int i = 0; i < 3; ++i) { fwd(); bwd(); }
+    CK(hipEventRecord(e0, nullptr)); for (int i = 0; i < 20; ++i) fwd(); CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); const float f_us = ms / 20 * 1e3f;
+    CK(hipEventRecord(e0, nullptr)); for (int i = 0; i < 20; ++i) bwd(); CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1)); const float b_us = ms / 20 * 1e3f;
+    std::vector<uint16_t> hd_(T * 3 * hd); CK(hipMemcpy(hd_.data(), dqkv, T * 3 * hd * 2, hipMemcpyDeviceToHost));
+    double cks = 0; long bad = 0; for (auto x : hd_) { const float f = bf2f(x); if (!(f == f)) ++bad; cks += fabs(f); }
+    printf("packed_mix     T=%ld: fwd %7.1f us (%.2f TB/s of q,k,v,o)  bwd %7.1f us (%.2f TB/s of 8 tensors)  sum|dqkv|=%.6e nan=%ld\n", (long)T, f_us,
+           4.0 * T * hd * 2 / f_us / 1e6, b_us, 8.0 * T * hd * 2 / b_us / 1e6, cks, bad);
   }
   return 0;
 }
