@@ -21,7 +21,7 @@ struct AttnParams {
   int64_t b, h, lq, lk;
   int64_t q_stride, k_stride, v_stride, dq_stride, dk_stride, dv_stride;
   float scale;
-  uint32_t drop_thresh;   // attention-probability dropout (0 = off)
+  uint32_t drop_thresh;   // attention-probability dropout: 8-bit threshold, P(drop) = drop_thresh / 256 (0 = off)
   float keep_scale;
   uint64_t seed;
   uint32_t grid_q, grid_pairs;   // pipelined forward: 1-D grid of grid_q query blocks x grid_pairs (batch, head) pairs
@@ -201,18 +201,35 @@ struct TileRegs {
   }
 };
 
-// attention-probability dropout: one 32-bit hash word decides TWO adjacent keys (16-bit thresholds), so the
-// per-element cost next to the MFMAs is ~1 integer multiply.  word = f(seed, (b,h,q), key >> 1); the
-// same function is evaluated by forward, dQ and dK/dV kernels (nothing is stored).
+// Attention-probability dropout, replayable: ONE 32-bit hash word decides a 2 x 2 tile of (query, key) pairs through
+// four 8-bit fields (an element is dropped when its field < th8: P(drop) = th8 / 256, the keep scale uses that
+// quantised rate).  word(q, k) = lowbias32(base + (q >> 1) * C1 + (k >> 1) * C2), base = f(seed, slab) with slab =
+// the (batch, head) identity; field index = 2 * (q & 1) + (k & 1), i.e. bits [16 (q&1) + 8 (k&1), +8).
+// The same function is evaluated by the forward, dQ and dK/dV kernels (nothing is stored); the 2 x 2 tile makes it
+// cost ONE hash per TWO elements in both register layouts: query-on-lane kernels hold keys (k, k+1) of one query in
+// adjacent accumulator registers (halfword 16 (q&1), bytes 0 / 1), key-on-lane kernels hold queries (q, q+1) of one
+// key (shift 8 (k&1), bytes 0 / 2).
+constexpr uint32_t kDropC1 = 0x9E3779B1u, kDropC2 = 0x85EBCA77u, kDropC3 = 0xC2B2AE3Du;
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {   // one multiply round: enough for a dropout mask
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
   return x;
 }
-__device__ __forceinline__ uint32_t drop_word(uint32_t seed, uint32_t qmix, uint32_t keypair) {
-  return lowbias32((qmix + keypair * 0x85EBCA77u) ^ seed);
+__device__ __forceinline__ uint32_t drop_base(uint64_t seed, int64_t slab) {
+  return ((uint32_t)seed ^ (uint32_t)(seed >> 32)) + (uint32_t)slab * kDropC3;
 }
-__device__ __forceinline__ float drop_mul16(uint32_t word, int half, uint32_t th16, float ks) {
-  return ((word >> (16 * half)) & 0xFFFFu) >= th16 ? ks : 0.f;
+// multiplier of a kept / dropped element from an 8-bit field
+__device__ __forceinline__ float drop_keep8(uint32_t field, uint32_t th8, float ks) { return (field & 0xFFu) >= th8 ? ks : 0.f; }
+// query-on-lane layout: multipliers of keys (k, k+1), k even, for the lane's query q.  u = base + (q>>1) C1 + (k>>1) C2
+__device__ __forceinline__ void drop_pair_q(uint32_t u, int q_odd, uint32_t th8, float ks, float& m0, float& m1) {
+  const uint32_t w = lowbias32(u) >> (16 * q_odd);
+  m0 = drop_keep8(w, th8, ks);
+  m1 = drop_keep8(w >> 8, th8, ks);
+}
+// key-on-lane layout: multipliers of queries (q, q+1), q even, for the lane's key k
+__device__ __forceinline__ void drop_pair_k(uint32_t u, int k_odd, uint32_t th8, float ks, float& m0, float& m1) {
+  const uint32_t w = lowbias32(u) >> (8 * k_odd);
+  m0 = drop_keep8(w, th8, ks);
+  m1 = drop_keep8(w >> 16, th8, ks);
 }
 
 // exchange between the two 32-lane halves of the wave on the VALU (v_permlane32_swap) instead of an LDS

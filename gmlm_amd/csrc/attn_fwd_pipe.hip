@@ -162,8 +162,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m = 0.f, l = 0.f;      // reference max (log2 domain, bf16-representable, identical in both half-waves) / this half-wave's partial row sum
-  const uint32_t qmix = (uint32_t)(lse_base + q_row) * 0x9E3779B1u;
-  const uint32_t seed32 = (uint32_t)p.seed ^ (uint32_t)(p.seed >> 32);
+  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;   // dropout hash input of the lane's query
+  const int q_odd = (int)(q_row & 1);
   const int nunits = (kvlen + 31) >> 5;       // 32-key score blocks that hold at least one valid key
   const int ntiles = (nunits + 1) >> 1;
   const int last_valid = kvlen - 32 * (nunits - 1);   // valid keys of the last block (1..32)
@@ -208,9 +208,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
 #endif
     float d0 = e0, d1 = e1;
     if (DROP) {
-      const uint32_t wd = drop_word(seed32, qmix, (uint32_t)((32 * u + acc_row(i, h)) >> 1));
-      d0 = e0 * drop_mul16(wd, 0, p.drop_thresh, p.keep_scale);
-      d1 = e1 * drop_mul16(wd, 1, p.drop_thresh, p.keep_scale);
+      float m0, m1;
+      drop_pair_q(dq_u + (uint32_t)(16 * u + (acc_row(i, 0) >> 1)) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
+      d0 = e0 * m0;
+      d1 = e1 * m1;
     }
     pc[i >> 3][i & 7] = (__bf16)d0;
     pc[i >> 3][(i & 7) + 1] = (__bf16)d1;

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <random>
 #include <string>
 #include <vector>
@@ -146,7 +147,13 @@ int main(int argc, char** argv) {
     const int64_t nseq = 1257, h = 12, d = 64, hd = h * d;
     std::vector<int32_t> cu(nseq + 1, 0);
     double pairs = 0;
-    for (int64_t i = 0; i < nseq; ++i) { const int len = 16 + (int)(rng() % 113); cu[i + 1] = cu[i] + len; pairs += (double)len * len; }
+    std::vector<int> lens(nseq);
+    for (auto& x : lens) x = 16 + (int)(rng() % 113);
+    std::sort(lens.begin(), lens.end(), [](int a, int b) { return a > b; });      // the encoder batches by length (descending)
+    for (int64_t i = 0; i < nseq; ++i) { cu[i + 1] = cu[i] + lens[i]; pairs += (double)lens[i] * lens[i]; }
+    // capacity classes (rows rounded up to 32): contiguous ranges of the sorted batch
+    std::vector<std::pair<int64_t, int64_t>> cls;      // (first sequence, count)
+    for (int64_t i = 0, j; i < nseq; i = j) { for (j = i; j < nseq && (lens[j] + 31) / 32 == (lens[i] + 31) / 32; ++j) {} cls.push_back({i, j - i}); }
     const int64_t T = cu[nseq];
     std::vector<uint16_t> hqkv(T * 3 * hd), hgo(T * hd);
     for (auto& x : hqkv) x = f2bf(nd(rng) * 0.5f);
@@ -160,8 +167,14 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dcu, cu.data(), (nseq + 1) * 4, hipMemcpyHostToDevice));
     const float scale = 0.125f;
     auto fwd = [&]() { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, o, lse, GMLM_BF16, dcu, 128, nullptr)); };
-    auto bwd = [&]() { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77,
-                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr)); };
+    const bool by_class = getenv("GMLM_BENCH_CLASSES") != nullptr;
+    auto bwd = [&]() {
+      if (!by_class) { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77,
+                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr)); return; }
+      for (auto& c : cls)      // one call per capacity class: same tensors, cu_seqlens sub-range, the class's own max_len
+        GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77,
+                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr));
+    };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms;
     for (int i = 0; i < 3; ++i) { fwd(); bwd(); }
