@@ -316,13 +316,15 @@ def _pmc_traffic(key):
     return d.get(key, {}).get("hbm_bytes_per_launch")
 
 
-def _pmc_attn(kernel_prefix):
+def _pmc_attn(kernel_prefix, grid=None):
     """PMC MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)) of an attention kernel from the
-    committed profile (profiles/rNN_attn_pmc.json, made by tools/pmc_attn.py); None if absent."""
+    committed profile (profiles/rNN_attn_pmc.json, made by tools/pmc_attn.py); None if absent.  ``grid``: total threads of the
+    launch (several shapes run the same kernel in the profile)."""
     d, name = _profile_json(["r02_attn_pmc.json"])
     for k, v in d.items():
-        if k.startswith(kernel_prefix):
-            return {"mfma_busy": v.get("mfma_util"), "valu_per_mfma": v.get("valu_per_mfma"), "profile": "profiles/" + name}
+        if k.startswith(kernel_prefix) and (grid is None or k.endswith("grid=%d" % grid)):
+            return {"mfma_busy": v.get("mfma_util"), "mfma_busy_useful_flops": v.get("mfma_util_useful"), "valu_per_mfma": v.get("valu_per_mfma"),
+                    "profile": "profiles/" + name}
     return None
 
 
@@ -596,17 +598,17 @@ def main():
                 "bound": "mfma", "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                 "cross_attention_fwd": {"kernel": "attn_fwd_pipe_kernel<96, 8> (h=8, d=96, N=20,804, no mask: padded = executed flops)",
                                         "achieved": xa["fwd_TFLOPs"], "frac": xa["fwd_frac_mfma_peak"], "avg_launch_ms": xa["fwd_ms"],
-                                        "pmc": _pmc_attn("attn_fwd_pipe_kernel<96, 8")},
+                                        "pmc": _pmc_attn("attn_fwd_pipe_kernel<96, 8", 82 * 8 * 512)},
                 "cross_attention_bwd": {"kernel": "attn_delta + attn_bwd_dq + attn_bwd_dkv (10 B h L^2 d convention; 14 executed: S is recomputed in both)",
                                         "achieved": xa["bwd_TFLOPs"], "frac": xa["bwd_frac_mfma_peak"], "avg_launch_ms": xa["bwd_ms"],
                                         "executed_TFLOPs": round(xa["bwd_TFLOPs"] * 1.4, 1),
-                                        "pmc_dq": _pmc_attn("attn_bwd_dq_kernel<unsigned short, 96, 8"),
-                                        "pmc_dkv": _pmc_attn("attn_bwd_dkv_kernel<unsigned short, 96, 8")},
-                "masked_mha_fwd": {"kernel": "attn_fwd_kernel<bf16, 64, 4> (B=32, h=12, L=512, d=64, kv_len ~ U[256,512])",
+                                        "pmc_dq": _pmc_attn("attn_bwd_dq_kernel<unsigned short, 96, 8", 82 * 8 * 512),
+                                        "pmc_dkv": _pmc_attn("attn_bwd_dkv_kernel<unsigned short, 96, 8", 82 * 8 * 512)},
+                "masked_mha_fwd": {"kernel": "attn_fwd_pipe_kernel<64, 4> (B=32, h=12, L=512, d=64, kv_len ~ U[256,512])",
                                    "achieved_padded": mh["fwd_TFLOPs"], "frac_padded": mh["fwd_frac_mfma_peak"],
                                    "achieved_executed": mh.get("fwd_TFLOPs_executed"), "avg_launch_ms": mh["fwd_ms"],
                                    "note": "100 MB of q/k/v/o for 18 GF executed: this shape sits at the HBM/MFMA ridge (257 flop/B vs 312)",
-                                   "pmc": _pmc_attn("attn_fwd_kernel<unsigned short, 64, 4")}}
+                                   "pmc": _pmc_attn("attn_fwd_pipe_kernel<64, 4", 4 * 384 * 256)}}
     if rank == 0 and world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and args.workload == "squirrel":
         # the same step with fp32 operands (the dtype the 1e-4 parity bar is stated in)
         args32 = argparse.Namespace(**{**vars(args), "dtype": "f32"})

@@ -244,6 +244,18 @@ __device__ __forceinline__ float xhalf_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// max of the 16 registers of a 32x32 accumulator tile (v_max3_f32 chain)
+__device__ __forceinline__ float max16(const f32x16& s) {
+  float a = fmaxf(fmaxf(s[0], s[1]), s[2]);
+  float b = fmaxf(fmaxf(s[3], s[4]), s[5]);
+  a = fmaxf(fmaxf(a, s[6]), s[7]);
+  b = fmaxf(fmaxf(b, s[8]), s[9]);
+  a = fmaxf(fmaxf(a, s[10]), s[11]);
+  b = fmaxf(fmaxf(b, s[12]), s[13]);
+  a = fmaxf(fmaxf(a, s[14]), s[15]);
+  return fmaxf(a, b);
+}
+
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kDefer = 6.f;   // log2 units: skip the online-softmax rescale while the max grows by < 2^6
 constexpr float kLn2 = 0.6931471805599453f;

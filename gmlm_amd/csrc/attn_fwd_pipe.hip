@@ -27,17 +27,6 @@
 
 namespace gmlm {
 
-__device__ __forceinline__ float max16(const f32x16& s) {
-  float a = fmaxf(fmaxf(s[0], s[1]), s[2]);
-  float b = fmaxf(fmaxf(s[3], s[4]), s[5]);
-  a = fmaxf(fmaxf(a, s[6]), s[7]);
-  b = fmaxf(fmaxf(b, s[8]), s[9]);
-  a = fmaxf(fmaxf(a, s[10]), s[11]);
-  b = fmaxf(fmaxf(b, s[12]), s[13]);
-  a = fmaxf(fmaxf(a, s[14]), s[15]);
-  return fmaxf(a, b);
-}
-
 // round-to-nearest bf16 value of x, as f32
 __device__ __forceinline__ float bf16_round(float x) { return (float)(__bf16)x; }
 

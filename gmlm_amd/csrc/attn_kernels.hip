@@ -627,6 +627,103 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// forward, sequences of <= 128 tokens (bf16): ONE workgroup per (sequence, head), Q / K / V resident in LDS (same
+// staging as attn_bwd_short_kernel: coalesced 16-byte pieces, all loads in flight at once, one barrier, operand
+// fragments from LDS).  All keys of the sequence are present, so the softmax is two plain passes over the score
+// blocks held in registers (row max, then exp / sum): no running rescale.
+// ------------------------------------------------------------------------------------------------
+template <int D, bool DROP, int R>
+__global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
+  using T = bf16_t;
+  constexpr int NT = 2 * R, PITCH = D + Pad<T>::v, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* tk = reinterpret_cast<T*>(smem_raw);
+  T* tv = tk + R * PITCH;
+  T* tq = tv + R * PITCH;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int64_t b = blockIdx.x / p.h, hd = blockIdx.x % p.h;
+  int64_t lq_, lk_, qbase, kbase, lse_base;
+  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
+  int64_t kvlen = lk_;
+  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
+  const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
+  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
+  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
+  const int lq = (int)lq_, lk = (int)lk_, kvl = (int)kvlen;
+  uint4 rk[PER], rv[PER], rq[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
+    rk[k] = rv[k] = rq[k] = make_uint4(0, 0, 0, 0);
+    if (row < lk) {
+      rk[k] = *reinterpret_cast<const uint4*>(kg + (uint32_t)(row * (int)p.k_stride + col));
+      rv[k] = *reinterpret_cast<const uint4*>(vg + (uint32_t)(row * (int)p.v_stride + col));
+    }
+    if (row < lq) rq[k] = *reinterpret_cast<const uint4*>(qg + (uint32_t)(row * (int)p.q_stride + col));
+  }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
+    *reinterpret_cast<uint4*>(tk + row * PITCH + col) = rk[k];
+    *reinterpret_cast<uint4*>(tv + row * PITCH + col) = rv[k];
+    *reinterpret_cast<uint4*>(tq + row * PITCH + col) = rq[k];
+  }
+  __syncthreads();
+  if (w * 32 >= lq) return;                                   // (no barrier below)
+  const int q_row = w * 32 + r;
+  RowFrag<T, D> qf;
+#pragma unroll
+  for (int s = 0; s < D / 16; ++s) qf.v[s] = *reinterpret_cast<const bf16x8*>(tq + q_row * PITCH + 16 * s + 8 * h);
+  const float sl2 = p.scale * kLog2e;
+  const int nblk = (kvl + 31) / 32;                           // block-uniform
+  f32x16 s[NB];
+  float rmax = -INFINITY;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    if (kb >= nblk) break;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    mma_rows<D>(tk, PITCH, kb * 32, qf, s[kb], r, h);
+    if ((kb + 1) * 32 > kvl) {                                // the block that straddles kv_len
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = kb * 32 + acc_row(i, h) < kvl ? s[kb][i] : -INFINITY;
+    }
+    rmax = fmaxf(rmax, max16(s[kb]));
+  }
+  const float m = nblk > 0 ? xhalf_max(rmax) * sl2 : 0.f;    // finite when any key is valid
+  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
+  const int q_odd = q_row & 1;
+  f32x16 o[DB];
+#pragma unroll
+  for (int d = 0; d < DB; ++d)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
+  float l = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < NB; ++kb) {
+    if (kb >= nblk) break;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const float e0 = fast_exp2(fmaf(s[kb][i], sl2, -m)), e1 = fast_exp2(fmaf(s[kb][i + 1], sl2, -m));   // masked: exp2(-inf) = 0
+      l += e0 + e1;                                           // the normaliser uses the un-dropped probabilities
+      float m0 = 1.f, m1 = 1.f;
+      if (DROP) drop_pair_q(dq_u + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
+      s[kb][i] = e0 * m0;
+      s[kb][i + 1] = e1 * m1;
+    }
+    mma_acc<D>(tv, PITCH, kb * 32, s[kb], o, lane);
+  }
+  l = xhalf_sum(l);
+  if (q_row < lq) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
+    if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
+  }
+}
+
 // 8-bit dropout threshold: P(drop) = th / 256 (|error| <= 2e-3: 0.1 -> 0.1016, 0.3 -> 0.3008), keep scale uses the quantised rate
 static inline uint32_t drop8(float p) { long t = lroundf(p * 256.f); return (uint32_t)(t < 0 ? 0 : (t > 255 ? 255 : t)); }
 
@@ -707,6 +804,30 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
 #ifdef GMLM_ATTN_STAMP
   p.delta = static_cast<float*>(g_stamp_buffer);
 #endif
+  if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && (cu_seqlens ? max_len : lk) <= 128 && b * h >= 512) {
+    // short sequences, enough of them to fill the chip: Q / K / V resident in LDS, one barrier (attn_fwd_short_kernel)
+    static bool attr_set = false;
+    auto lds_of = [](int r) { return (size_t)3 * r * (64 + 8) * sizeof(bf16_t); };
+    if (!attr_set) {
+#define GMLM_SHORT_ATTR(RR)                                                                                                        \
+      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
+      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, false, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR)));
+      GMLM_SHORT_ATTR(32) GMLM_SHORT_ATTR(64) GMLM_SHORT_ATTR(96) GMLM_SHORT_ATTR(128)
+#undef GMLM_SHORT_ATTR
+      attr_set = true;
+    }
+    const int64_t rk_ = cu_seqlens ? max_len : lk, rmax = rows_q > rk_ ? rows_q : rk_;
+    const int top = (int)((rmax + 31) / 32) * 32;
+#define GMLM_SHORT_LAUNCH(RR)                                                                                                      \
+    if (RR == top) {                                                                                                               \
+      if (p.drop_thresh) attn_fwd_short_kernel<64, true, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                   \
+      else attn_fwd_short_kernel<64, false, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                                 \
+    }
+    GMLM_SHORT_LAUNCH(128) GMLM_SHORT_LAUNCH(96) GMLM_SHORT_LAUNCH(64) GMLM_SHORT_LAUNCH(32)
+#undef GMLM_SHORT_LAUNCH
+    GMLM_LAUNCH_CHECK();
+    return GMLM_OK;
+  }
   if (dtype == GMLM_BF16 && (d == 96 || rows_q > 128)) {
     // software-pipelined LDS-DMA kernel (attn_fwd_pipe.hip): CrossAttention geometry (d = 96: +40-45 % at N = 5k-20k
     // against attn_fwd_kernel) and BERT geometry beyond 128 tokens (d = 64: +8 % at L = 512, +15 % at L = 2048).

@@ -166,8 +166,12 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(qkv, hqkv.data(), T * 3 * hd * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(go, hgo.data(), T * hd * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(dcu, cu.data(), (nseq + 1) * 4, hipMemcpyHostToDevice));
     const float scale = 0.125f;
-    auto fwd = [&]() { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, o, lse, GMLM_BF16, dcu, 128, nullptr)); };
     const bool by_class = getenv("GMLM_BENCH_CLASSES") != nullptr;
+    auto fwd = [&]() {
+      if (!by_class) { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, o, lse, GMLM_BF16, dcu, 128, nullptr)); return; }
+      for (auto& c : cls)
+        GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, o, lse, GMLM_BF16, dcu + c.first, lens[c.first], nullptr));
+    };
     auto bwd = [&]() {
       if (!by_class) { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77,
                                               dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr)); return; }
