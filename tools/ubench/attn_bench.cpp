@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
   std::mt19937 rng(1234);
   std::normal_distribution<float> nd(0.f, 1.f);
   for (const Case& c : cases) {
-    if (only && !strstr(c.tag, only)) continue;
+    if (only && (only[0] == '=' ? strcmp(c.tag, only + 1) != 0 : !strstr(c.tag, only))) continue;   // "=name": exact match
     const int64_t n = c.b * c.l * c.h * c.d, rows = c.b * c.l;
     std::vector<uint16_t> hq(n), hk(n), hv(n), hgo(n);
     std::vector<float> fq(n), fk(n), fv(n), fgo(n);
@@ -142,7 +142,7 @@ int main(int argc, char** argv) {
     (void)hipFree(qf); (void)hipFree(kf); (void)hipFree(vf); (void)hipFree(of); (void)hipFree(gof); (void)hipFree(dqf); (void)hipFree(dkf); (void)hipFree(dvf);
     (void)hipFree(lse); (void)hipFree(lsef); (void)hipFree(ws); if (len) (void)hipFree(len);
   }
-  if (!only || strstr("packed_mix", only)) {
+  if (!only || strstr("packed_mix", only[0] == '=' ? only + 1 : only)) {
     // the in-step BERT batch: 1,257 sequences of 16..128 tokens packed back to back (cu_seqlens), fused QKV rows, h = 12, d = 64, p = 0.1
     const int64_t nseq = 1257, h = 12, d = 64, hd = h * d;
     std::vector<int32_t> cu(nseq + 1, 0);
