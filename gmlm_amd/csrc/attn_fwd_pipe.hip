@@ -53,7 +53,13 @@ template <int D, int NW, bool ISV>
 struct DmaPlan {
   using G = Img<D>;
   static constexpr int PER = G::NDMA / NW;
-  uint32_t boff[PER];   // BYTE offset of this lane's source chunk inside a tile: 2 * (row * stride + 8 * chunk)
+  // Piece k covers rows STEP * k + (rows of piece 0), and STEP is a multiple of 16, so the swizzle (a function of the low
+  // four row bits) and with it the lane's column are the same in every piece: ONE per-lane byte offset serves all pieces,
+  // piece k adds the wave-uniform k * STEP * stride to the SGPR base.
+  static constexpr int STEP = 64 * NW / G::CPR;
+  static_assert(STEP % 16 == 0, "pieces must preserve the swizzle phase");
+  uint32_t boff0;       // BYTE offset of this lane's source chunk inside piece 0: 2 * (row * stride + 8 * chunk)
+  int64_t stride_;
   __device__ static __forceinline__ void where(int k, int w, int lane, int& row, int& col) {
     const int idx = 64 * (w + NW * k) + lane, slot = idx % G::CPR;
     row = idx / G::CPR;
@@ -62,12 +68,10 @@ struct DmaPlan {
     col = 8 * chunk;
   }
   __device__ __forceinline__ void init(int64_t g_stride, int w, int lane) {
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      int row, col;
-      where(k, w, lane, row, col);
-      boff[k] = 2u * (uint32_t)(row * g_stride + col);
-    }
+    int row, col;
+    where(0, w, lane, row, col);
+    boff0 = 2u * (uint32_t)(row * g_stride + col);
+    stride_ = g_stride;
   }
   // LDS-DMA through inline asm on purpose: hipcc orders a builtin LDS-DMA against every later ds_read it cannot prove
   // disjoint (s_waitcnt vmcnt(0) right behind the DMA), which exposes the whole load latency.  The asm form is
@@ -78,9 +82,10 @@ struct DmaPlan {
   // 32-bit byte offset: no VALU address arithmetic at all inside the MFMA gaps.
   __device__ __forceinline__ void piece_fast(int k, const bf16_t* base /* g + row0 * stride, wave-uniform */, uint32_t tile, int w) const {
     const uint32_t dst_u = __builtin_amdgcn_readfirstlane(tile + 1024u * (uint32_t)(w + NW * k));
+    const bf16_t* src = base + (int64_t)(k * STEP) * stride_;          // wave-uniform: scalar add
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(boff[k]), "s"(base), "s"(dst_u) : "memory");
+                 : "=&s"(keep) : "v"(boff0), "s"(src), "s"(dst_u) : "memory");
   }
   // General form (prologue / tail): rows past the slab re-read its last row (finite data; their scores are masked /
   // their probabilities are exactly 0).  g: start of the (batch, head) slab; limit: rows of the slab (>= 1, row0 < limit).
@@ -108,6 +113,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   using G = Img<D>;
   constexpr int KT = 64, DB = D / 32, NQ = D / 16, NP = 2 * DB, NM = NQ + 1 + NP, RP = G::RP;
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dyn[];      // K ring [NB][TILE], then V ring [NB][TILE]
+#ifdef GMLM_ATTN_STAMP
+  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
+#endif
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   // 1-D grid of (query block, (batch, head) pair) items.  Workgroups are dealt round-robin over the 8 XCDs (id % 8 says
   // which ids share an XCD, hence an L2): the query blocks of one pair are mapped to ids with equal id % 8 and
@@ -117,7 +125,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   uint32_t qb, pair;
   if (nq > 1 && npairs % 8 == 0) { const uint32_t slot = id >> 3; pair = (slot / nq) * 8 + (id & 7); qb = slot % nq; }
   else { qb = id % nq; pair = id / nq; }
-  const int64_t b = pair / p.h, hd = pair % p.h;
+  const uint32_t nh = (uint32_t)p.h;
+  const int64_t b = pair / nh, hd = pair % nh;        // 32-bit division (the 64-bit form is ~80 scalar instructions)
   int64_t lq_, lk_, qbase, kbase, lse_base;
   seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
   if ((int64_t)qb * (NW * 32) >= lq_) return;                    // varlen: tile past this sequence (block-uniform)
@@ -134,6 +143,27 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   // Q' = bf16(Q * scale * log2 e): scores leave the MFMA in the log2 domain (one more bf16 rounding of q, the size of
   // the rounding q already carries).  The extra contraction step [1 0 .. 0] x [-m 0 .. 0]^T subtracts the reference
   // max m (kept bf16-representable, so the product is exact) inside the MFMA chain: p = exp2(s') needs no fma.
+  const int nunits = (kvlen + 31) >> 5;       // 32-key score blocks that hold at least one valid key
+  const int ntiles = (nunits + 1) >> 1;
+  const int last_valid = kvlen - 32 * (nunits - 1);   // valid keys of the last block (1..32)
+  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem_dyn;
+#ifdef GMLM_ATTN_STAMP
+  uint64_t t_steps = 0, t_stage = 0, t_bar = 0, t_load = 0, t0_, t1_, t2_, t3_, t4_, t_main = 0, t_tail = 0, t_loop_end = 0, t_landed = 0;
+#define STAMP(x) x = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(x)
+#endif
+  // The first tiles are requested before anything else (K tile 0, V tile 0, K tile 1): their latency runs under the
+  // Q fetch and the lane-constant set-up below instead of behind it.
+  DmaPlan<D, NW, false> kd;
+  DmaPlan<D, NW, true> vd;
+  kd.init(p.k_stride, w, lane);
+  vd.init(p.v_stride, w, lane);
+  if (ntiles > 0) {
+    kd.issue(kg, p.k_stride, 0, lk_, lds0, w, lane);
+    vd.issue(vg, p.v_stride, 0, lk_, lds0 + (uint32_t)(NB * G::TILE), w, lane);
+    if (ntiles > 1) kd.issue(kg, p.k_stride, KT, lk_, lds0 + (uint32_t)G::TILE, w, lane);
+  }
   RowFrag<T, D> qf;
   qf.load(qg, q_ok, h);
   const float sl2 = p.scale * kLog2e;
@@ -144,7 +174,19 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   bf16x8 ones, qx;
 #pragma unroll
   for (int j = 0; j < 8; ++j) { ones[j] = (__bf16)0.f; qx[j] = (__bf16)0.f; }
-  if (h == 0) ones[0] = (__bf16)1.f;
+  // Key masking rides in the same extra contraction step: its second column is [key masked ? 1 : 0] x [-2^100], so a masked
+  // key's score leaves the MFMA chain at about -1.3e30 and its probability is exp2(.) = 0 exactly, with no compare / select
+  // per score.  Only the last block of a sequence can hold masked keys: `ones` (no key masked) serves every other block.
+  if (h == 0) { ones[0] = (__bf16)1.f; qx[1] = (__bf16)(-0x1p100f); }
+  auto ones_for = [&](int blk) {                       // A fragment of the extra step for block blk (prologue / tail only)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));                   // opaque: keeps the mask fragment out of the registers held across the hot loop
+    bf16x8 a;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = (__bf16)0.f;
+    if (lane_t < 32) { a[0] = (__bf16)1.f; a[1] = (blk == nunits - 1 && lane_t >= last_valid) ? (__bf16)1.f : (__bf16)0.f; }
+    return a;
+  };
   f32x16 o[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -153,12 +195,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   float m = 0.f, l = 0.f;      // reference max (log2 domain, bf16-representable, identical in both half-waves) / this half-wave's partial row sum
   const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;   // dropout hash input of the lane's query
   const int q_odd = (int)(q_row & 1);
-  const int nunits = (kvlen + 31) >> 5;       // 32-key score blocks that hold at least one valid key
-  const int ntiles = (nunits + 1) >> 1;
-  const int last_valid = kvlen - 32 * (nunits - 1);   // valid keys of the last block (1..32)
   // lane constants of the LDS operand reads: ABSOLUTE LDS byte addresses of the lane's spot in tile buffer 0 of the K
   // ring; everything else (buffer, V ring, row block, contraction step) is an immediate offset in the hot loop
-  const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) void*)smem_dyn;
   uint32_t koff[NQ];                                    // K A-operand, contraction step s: row r, chunk 2s + h
 #pragma unroll
   for (int s = 0; s < NQ; ++s) koff[s] = lds0 + r * RP + (((2 * s + h) ^ G::fk(r)) << 4);
@@ -205,18 +243,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     pc[i >> 3][i & 7] = (__bf16)d0;
     pc[i >> 3][(i & 7) + 1] = (__bf16)d1;
   };
-  auto softmax_block = [&](const f32x16& sc, bf16x8 (&pc)[2], int u) {
-    float rs0 = 0.f, rs1 = 0.f, pe0 = 0.f, pe1 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sm_pair(sc, pc, u, j, rs0, rs1, pe0, pe1);
-    l += (rs0 + pe0) + (rs1 + pe1);
-  };
   // S'^T(block) = K(rows row0..row0+31) Q'^T - m: the max column first, then the D/16 real contraction steps
-  auto qk_unit = [&](uint32_t koffs, f32x16& s) {
+  auto qk_unit = [&](uint32_t koffs, f32x16& s, const bf16x8& ones_a) {
     f32x16 z;
 #pragma unroll
     for (int i = 0; i < 16; ++i) z[i] = 0.f;
-    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qx, z, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, qx, z, 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < NQ; ++t) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag(koffs, t), qf.v[t], s, 0, 0, 0);
   };
@@ -238,11 +270,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   // the pending PV(u-1) has been accumulated, so that everything summed so far is at the old scale exactly once
   // (guide T13 hazard).  Returns alpha (1 when nothing moved).
   auto check = [&](f32x16& sc, int u, bool& rare) {
-    if (u == nunits - 1 && last_valid < 32) {           // only the last block can hold masked keys (wave-uniform)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sc[i] = acc_row(i, h) < last_valid ? sc[i] : -INFINITY;
-    }
-    const float g = max16(sc);
+    const float g = max16(sc);                          // masked keys sit at about -1.3e30 (see ones_for)
     rare = u == 0 || !__all(g <= kDefer);
     float alpha = 1.f;
     if (rare) {
@@ -266,22 +294,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
       for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
   };
 
-  // ---- generic step (prologue / tail): same work, no interleave ------------------------------------------------
+  // ---- steady-state step: PV(u-1) and QK(u+1) on the matrix pipe under the softmax of block u ---------------
   //  sc: scores of block u (log2 domain, reference max subtracted)   pc: packed probabilities of block u (output)
   //  sn: receives the scores of block u+1                              pp: packed probabilities of block u-1
-  auto step = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u, bool has_pv, bool has_qk,
-                  uint32_t voffs, uint32_t koffs) {
-    bool rare;
-    const float alpha = check(sc, u, rare);
-    if (has_pv) pv_unit(voffs, pp);
-    if (has_qk) qk_unit(koffs, sn);
-    softmax_block(sc, pc, u);
-    if (rare) scale_o(alpha);
-  };
-  // ---- steady-state step: PV(u-1) and QK(u+1) on the matrix pipe under the softmax of block u ---------------
+  //  ones_a: extra-step A fragment of block u+1.  Every step does all of it: at the ends of the sequence PV(-1) runs with
+  //  P = 0 against a loaded V tile and QK(nunits) produces scores nobody reads.
   auto step_full = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, const bf16x8 (&pp)[2], int u,
-                       auto voffs_c, auto koffs_c, auto&& gap_hook) {
-    constexpr uint32_t voffs = decltype(voffs_c)::value, koffs = decltype(koffs_c)::value;   // compile-time: ds_read offset fields
+                       auto voffs_c, auto koffs_c, const bf16x8& ones_a, auto&& gap_hook) {
+    const uint32_t voffs = voffs_c, koffs = koffs_c;   // integral_constant in the hot loop (folds into the ds_read offset field), runtime in the tail
     // operand reads of the first MFMAs go out before the check: its ~12 VALU instructions cover their latency
     bf16x8 ka[NQ];
 #pragma unroll
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
         f32x16 z;
 #pragma unroll
         for (int i = 0; i < 16; ++i) z[i] = 0.f;
-        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, qx, z, 0, 0, 0);
+        sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, qx, z, 0, 0, 0);
       } else if (g <= NQ) {
         sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[g - 1], qf.v[g - 1], sn, 0, 0, 0);
       } else {
@@ -326,46 +346,37 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     if (rare) scale_o(alpha);
   };
 
-#ifdef GMLM_ATTN_STAMP
-  uint64_t t_steps = 0, t_stage = 0, t_bar = 0, t_load = 0, t0_, t1_, t2_, t3_, t4_;
-  const uint64_t t_begin = __builtin_amdgcn_s_memtime();
-#define STAMP(x) x = __builtin_amdgcn_s_memtime()
-#else
-#define STAMP(x)
-#endif
-  auto ks_a = [&](int t) { return lds0 + (uint32_t)((t % NB) * G::TILE); };                 // LDS address of K tile t's buffer
-  auto vs_a = [&](int t) { return lds0 + (uint32_t)((NB + t % NB) * G::TILE); };
-  DmaPlan<D, NW, false> kd;
-  DmaPlan<D, NW, true> vd;
-  kd.init(p.k_stride, w, lane);
-  vd.init(p.v_stride, w, lane);
   f32x16 sa, sb;
   bf16x8 pa[2], pb[2];
-  static_assert(NB == 2, "the parity-unrolled main loop assumes two buffers per operand");
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { pb[0][j] = (__bf16)0.f; pb[1][j] = (__bf16)0.f; }       // "P(-1)" = 0 for step 0's PV
+  static_assert(NB == 2, "the parity-unrolled loop assumes two buffers per operand");
   constexpr int PK = DmaPlan<D, NW, false>::PER;       // DMA pieces per tile and wave
   if (ntiles > 0) {
     // Invariant at the top of iteration i (steps 2i-1 and 2i; reads K tile i and V tile i-1): both are in LDS and
     // published; K tile i+1 and V tile i have not been requested.  The iteration requests them (K tile i+1 into the
     // buffer K tile i-1 left, V tile i into the buffer V tile i-2 left, both last read before the previous barrier),
     // waits for its own DMA and closes with the ONE barrier per 64 keys.
-    // prologue: K tile 0, V tile 0, K tile 1; QK(0); step 0
-    kd.issue(kg, p.k_stride, 0, lk_, ks_a(0), w, lane);
-    vd.issue(vg, p.v_stride, 0, lk_, vs_a(0), w, lane);
-    if (ntiles > 1) kd.issue(kg, p.k_stride, KT, lk_, ks_a(1), w, lane);
+    // prologue (tiles requested at the top of the kernel): QK(0); step 0
     dma_wait();
     __syncthreads();
+    STAMP(t_landed);
 #pragma unroll
     for (int s = 0; s < NQ; ++s) asm volatile("" :: "v"(qf.v[s]));   // Q has landed too: no vmcnt wait for it inside the loop
     if (wave_live) {
-      qk_unit(k_at(0, 0), sa);
-      step(sa, pa, sb, pb, 0, false, nunits > 1, v_at(0, 0), k_at(0, 32));
+      qk_unit(k_at(0, 0), sa, ones_for(0));
+      step_full(sa, pa, sb, pb, 0, std::integral_constant<uint32_t, (uint32_t)(NB * G::TILE)>{},
+                std::integral_constant<uint32_t, (uint32_t)(32 * RP)>{}, ones_for(1), [](int) {});
     }
     __syncthreads();                                    // every wave is done with K tile 0 before iteration 1 refills its buffer
-    // ---- main loop: both steps have a block ahead and a block behind, and the requested tiles are INTERIOR (all 64
-    // rows inside the slab), so the DMA pieces need no per-lane clamping.  Unrolled by the buffer parity: every LDS
-    // operand address is lane constant + immediate.
+    // ---- main loop.  HOT iterations: both steps have a block behind and a NON-LAST block ahead (so the extra-step
+    // fragment is the constant `ones`), and the requested tiles are INTERIOR (all 64 rows inside the slab: the DMA
+    // pieces need no per-lane clamping and ride in the MFMA gaps).  TAIL iterations (the last one or two): clamping
+    // DMA issued up front, the masked fragment where the next block is the last.  Unrolled by the buffer parity:
+    // every LDS operand address is lane constant + immediate.
     int i = 1;
-    auto hot = [&](int ii) { return 2 * ii + 1 < nunits && (int64_t)(ii + 2) * KT <= lk_; };
+    STAMP(t_main);
+    auto hot = [&](int ii) { return 2 * ii + 2 < nunits && (int64_t)(ii + 2) * KT <= lk_; };
     auto iteration = [&](auto par_c, int ii) {
       constexpr int PAR = decltype(par_c)::value;       // = ii & 1: K tile ii lives in K buffer PAR, V tile ii-1 in V buffer PAR ^ 1
       STAMP(t0_);
@@ -387,8 +398,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
       using KO1 = std::integral_constant<uint32_t, (uint32_t)(PAR * G::TILE + 32 * RP)>;
       STAMP(t1_);
       if (wave_live) {
-        step_full(sb, pb, sa, pa, 2 * ii - 1, VO0{}, KO0{}, dma_hook);
-        step_full(sa, pa, sb, pb, 2 * ii, VO1{}, KO1{}, [](int) {});
+        step_full(sb, pb, sa, pa, 2 * ii - 1, VO0{}, KO0{}, ones, dma_hook);
+        step_full(sa, pa, sb, pb, 2 * ii, VO1{}, KO1{}, ones, [](int) {});
       } else {
 #pragma unroll
         for (int g = 0; g < NM; ++g) dma_hook(g);
@@ -402,35 +413,44 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
       t_load += t1_ - t0_; t_steps += t2_ - t1_; t_stage += t3_ - t2_; t_bar += t4_ - t3_;
 #endif
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
     for (; hot(i + 1); i += 2) {                        // i is odd at the top; hot(i + 1) implies hot(i)
-      iteration(std::integral_constant<int, 1>{}, i);
-      iteration(std::integral_constant<int, 0>{}, i + 1);
+      iteration(P1{}, i);
+      iteration(P0{}, i + 1);
     }
-    if (hot(i)) {                                       // one more interior iteration (odd i)
-      iteration(std::integral_constant<int, 1>{}, i);
+    if (hot(i)) {                                       // one more hot iteration (odd i)
+      iteration(P1{}, i);
       ++i;
     }
-    // ---- tail: the last blocks and the (possibly partial) last tile: generic steps, clamping DMA
+    STAMP(t_tail);
+    // ---- tail (the last one or two iterations): same steps with run-time buffer offsets, clamping DMA issued up front
     for (; 2 * i - 1 < nunits; ++i) {
-      if (i + 1 < ntiles) kd.issue(kg, p.k_stride, (int64_t)(i + 1) * KT, lk_, ks_a(i + 1), w, lane);
-      if (i < ntiles) vd.issue(vg, p.v_stride, (int64_t)i * KT, lk_, vs_a(i), w, lane);
-      const int kb = i % NB, vb = (i - 1) % NB;
+      const int par = i & 1;
+      {
+        // (lane made opaque: otherwise the per-lane row / column of every clamped piece is hoisted out of this loop and
+        // held in registers across the hot loop)
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        if (i + 1 < ntiles) kd.issue(kg, p.k_stride, (int64_t)(i + 1) * KT, lk_, lds0 + (uint32_t)((par ^ 1) * G::TILE), w, lane_t);
+        if (i < ntiles) vd.issue(vg, p.v_stride, (int64_t)i * KT, lk_, lds0 + (uint32_t)((NB + par) * G::TILE), w, lane_t);
+      }
       if (wave_live) {
-        step(sb, pb, sa, pa, 2 * i - 1, true, 2 * i < nunits, v_at(vb, 0), k_at(kb, 0));
-        if (2 * i < nunits) step(sa, pa, sb, pb, 2 * i, true, 2 * i + 1 < nunits, v_at(vb, 32), k_at(kb, 32));
-        else pv_unit(v_at(vb, 32), pb);                                 // nunits even: last block retired here
+        const uint32_t vo = (uint32_t)((NB + (par ^ 1)) * G::TILE), ko = (uint32_t)(par * G::TILE);
+        step_full(sb, pb, sa, pa, 2 * i - 1, vo, ko, ones_for(2 * i), [](int) {});
+        if (2 * i < nunits) step_full(sa, pa, sb, pb, 2 * i, vo + (uint32_t)(32 * RP), ko + (uint32_t)(32 * RP), ones_for(2 * i + 1), [](int) {});
       }
       dma_wait();
       __syncthreads();
     }
-    if ((nunits & 1) && wave_live) pv_unit(v_at((ntiles - 1) % NB, 0), pa);   // nunits odd: last block = first half of the last V tile
+    // the last block's PV is still pending: block nunits-1 = rows 32 * ((nunits - 1) & 1) of V tile ntiles-1, its
+    // probabilities in pa (even block) / pb (odd block)
+    if (wave_live) {
+      if (nunits & 1) pv_unit(v_at((ntiles - 1) % NB, 0), pa);
+      else pv_unit(v_at((ntiles - 1) % NB, 32), pb);
+    }
   }
-#ifdef GMLM_ATTN_STAMP
-  if (lane == 0 && p.delta) {     // diagnostic build: p.delta = uint64 [waves][6]
-    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.delta) + ((size_t)blockIdx.x * NW + w) * 6;
-    dbg[0] = t_load; dbg[1] = t_steps; dbg[2] = t_stage; dbg[3] = t_bar; dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; dbg[5] = (uint64_t)nunits;
-  }
-#endif
+  STAMP(t_loop_end);
   if (q_ok) {
     l = xhalf_sum(l);
     const float inv = l > 0.f ? 1.f / l : 0.f;
@@ -439,6 +459,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
     if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
   }
+#ifdef GMLM_ATTN_STAMP
+  if (lane == 0 && p.delta) {     // diagnostic build: p.delta = uint64 [waves][12]
+    uint64_t* dbg = reinterpret_cast<uint64_t*>(p.delta) + ((size_t)blockIdx.x * NW + w) * 12;
+    dbg[0] = t_load; dbg[1] = t_steps; dbg[2] = t_stage; dbg[3] = t_bar; dbg[4] = __builtin_amdgcn_s_memtime() - t_begin; dbg[5] = (uint64_t)nunits;
+    dbg[6] = t_begin; dbg[3] = t_landed - t_begin; dbg[7] = t_main; dbg[8] = t_tail; dbg[9] = t_loop_end; dbg[10] = __builtin_amdgcn_s_memtime();
+    dbg[11] = ((uint64_t)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | (uint32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // XCC_ID, HW_ID
+  }
+#endif
 }
 
 template <int D, int NW, int NB>

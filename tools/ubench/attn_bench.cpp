@@ -95,17 +95,62 @@ int main(int argc, char** argv) {
       for (int64_t i = 0; i < rows * c.h; ++i) { const double e = fabs((double)hl[i] - rl[i]); if (!(e == e)) ++bad; else if (e > el) el = e; }
 #ifdef GMLM_ATTN_STAMP
       {
+        const int SL = 12;
         const size_t nwaves = (size_t)(c.l / 32 + 8) * c.b * c.h;
-        uint64_t* dbg; CK(hipMalloc(&dbg, nwaves * 6 * 8)); CK(hipMemset(dbg, 0, nwaves * 6 * 8));
+        uint64_t* dbg; CK(hipMalloc(&dbg, nwaves * SL * 8)); CK(hipMemset(dbg, 0, nwaves * SL * 8));
         gmlm_debug_set_stamp_buffer(dbg);
         GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, o, lse, GMLM_BF16, nullptr, 0, nullptr));
         CK(hipDeviceSynchronize());
         gmlm_debug_set_stamp_buffer(nullptr);
-        std::vector<uint64_t> hd(nwaves * 6); CK(hipMemcpy(hd.data(), dbg, nwaves * 6 * 8, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> hd(nwaves * SL); CK(hipMemcpy(hd.data(), dbg, nwaves * SL * 8, hipMemcpyDeviceToHost));
         double s[6] = {0, 0, 0, 0, 0, 0}; size_t cnt = 0;
-        for (size_t wv = 0; wv < nwaves; ++wv) if (hd[wv * 6 + 4]) { for (int t = 0; t < 6; ++t) s[t] += (double)hd[wv * 6 + t]; ++cnt; }
-        if (cnt) printf("%-14s var=%d stamps over %zu waves (mean cycles per wave): total %.0f | loop: load-issue %.0f  steps %.0f  lds-store %.0f  barrier %.0f | blocks/wave %.1f -> cycles per 32-key step %.0f\n",
-                        c.tag, var, cnt, s[4] / cnt, s[0] / cnt, s[1] / cnt, s[2] / cnt, s[3] / cnt, s[5] / cnt, s[1] / cnt / (s[5] / cnt));
+        // s_memtime counters are per XCD: normalise every wave's stamps to the earliest stamp of ITS XCD
+        uint64_t xmin[16]; for (auto& x : xmin) x = ~0ull;
+        for (size_t wv = 0; wv < nwaves; ++wv) if (hd[wv * SL + 4]) { const int xc = (int)(hd[wv * SL + 11] >> 32) & 15; if (hd[wv * SL + 6] < xmin[xc]) xmin[xc] = hd[wv * SL + 6]; }
+        uint64_t tmax = 0;
+        double pro = 0, mainl = 0, tail = 0, epi = 0;
+        for (size_t wv = 0; wv < nwaves; ++wv) if (hd[wv * SL + 4]) {
+          const uint64_t* d = &hd[wv * SL];
+          for (int t = 0; t < 6; ++t) s[t] += (double)d[t];
+          ++cnt;
+          const uint64_t x0 = xmin[(int)(d[11] >> 32) & 15];
+          if (d[10] - x0 > tmax) tmax = d[10] - x0;
+          pro += (double)(d[7] - d[6]); mainl += (double)(d[8] - d[7]); tail += (double)(d[9] - d[8]); epi += (double)(d[10] - d[9]);
+        }
+        if (cnt) {
+          printf("%-14s var=%d stamps over %zu waves (mean ticks per wave): total %.0f | loop: load-issue %.0f  steps %.0f  dma-wait %.0f  barrier %.0f | blocks/wave %.1f -> ticks per 32-key step %.0f\n",
+                 c.tag, var, cnt, s[4] / cnt, s[0] / cnt, s[1] / cnt, s[2] / cnt, s[3] / cnt, s[5] / cnt, s[1] / cnt / (s[5] / cnt));
+          printf("%-14s   kernel span %llu ticks (per-XCD clocks aligned at their first wave); per wave: prologue %.0f  main loop %.0f  tail %.0f  epilogue %.0f\n", c.tag,
+                 (unsigned long long)tmax, pro / cnt, mainl / cnt, tail / cnt, epi / cnt);
+          const int NBIN = 20; double alive[NBIN] = {0}; int starts[NBIN] = {0};
+          const double span = (double)tmax;
+          for (size_t wv = 0; wv < nwaves; ++wv) if (hd[wv * SL + 4]) {
+            const uint64_t* d = &hd[wv * SL];
+            const uint64_t x0 = xmin[(int)(d[11] >> 32) & 15];
+            const double a = (double)(d[6] - x0) / span * NBIN, b = (double)(d[10] - x0) / span * NBIN;
+            int sb = (int)a; if (sb >= NBIN) sb = NBIN - 1; ++starts[sb];
+            for (int bn = 0; bn < NBIN; ++bn) { const double lo = bn > a ? bn : a, hi = bn + 1 < b ? bn + 1 : b; if (hi > lo) alive[bn] += hi - lo; }
+          }
+          printf("%-14s   waves/SIMD alive per 1/20 of the span:", c.tag);
+          for (int bn = 0; bn < NBIN; ++bn) printf(" %.1f", alive[bn] / 1024.0);
+          printf("\n%-14s   wave starts per bin:", c.tag);
+          for (int bn = 0; bn < NBIN; ++bn) printf(" %d", starts[bn]);
+          printf("\n");
+          // one CU's timeline: the workgroups (wave 0 of each) that ran on the CU of the first stamped wave
+          uint32_t hw0 = 0; int xc0 = -1; int shown = 0;
+          for (size_t wv = 0; wv < nwaves && shown < 12; wv += 4) if (hd[wv * SL + 4]) {
+            const uint64_t* d = &hd[wv * SL];
+            const uint32_t hw = (uint32_t)d[11] & 0x0000ff00u /* CU_ID[11:8] + SH/SE bits below are in [15:12] */; const int xc = (int)(d[11] >> 32) & 15;
+            const uint32_t cu = ((uint32_t)d[11] >> 8) & 0xf, se = ((uint32_t)d[11] >> 13) & 0x7;
+            if (xc0 < 0) { xc0 = xc; hw0 = (se << 4) | cu; }
+            if (xc != xc0 || ((se << 4) | cu) != hw0) continue;
+            const uint64_t x0 = xmin[xc];
+            printf("%-14s   CU(xcc %d se %u cu %u) wg %zu: begin %llu  main %llu  tail %llu  loop-end %llu  end %llu\n", c.tag, xc, se, cu, wv / 4,
+                   (unsigned long long)(d[6] - x0), (unsigned long long)(d[7] - x0), (unsigned long long)(d[8] - x0), (unsigned long long)(d[9] - x0), (unsigned long long)(d[10] - x0));
+            ++shown;
+          }
+          (void)hw0;
+        }
         (void)hipFree(dbg);
       }
 #endif
