@@ -2,9 +2,10 @@
 ``node_features, edges, node_labels, node_texts, label_texts, train_masks, val_masks, test_masks``).
 
 Only what feeds the hot path is here: tensors, texts, masks, the ``RandomState(seed)`` split of
-main.py:792-808.  Text arrays are read WITHOUT unpickling (``allow_pickle=False``): files that store texts as
+main.py:792-808.  By default text arrays are read WITHOUT unpickling (``allow_pickle=False``): files that store texts as
 fixed-width unicode arrays load directly; object-dtype (pickled) text arrays are refused with an explicit error
-instead of executing a pickle.
+instead of executing a pickle.  ``allow_pickle=True`` is the reference's own behaviour (main.py:782) and is an explicit
+opt-in for files the caller produced and trusts.
 """
 from __future__ import annotations
 
@@ -38,15 +39,16 @@ class GraphData:
         return self
 
 
-def load_npz_dataset(npz_path: str, split_ratios: Optional[Tuple[float, float, float]] = None, seed: int = 42):
-    """-> (GraphData, num_features, num_classes), as ``load_npz_dataset`` in the reference."""
+def load_npz_dataset(npz_path: str, split_ratios: Optional[Tuple[float, float, float]] = None, seed: int = 42,
+                     allow_pickle: bool = False):
+    """-> (GraphData, num_features, num_classes), as ``load_npz_dataset`` in the reference (main.py:780-820)."""
     try:
-        d = np.load(npz_path, allow_pickle=False)
+        d = np.load(npz_path, allow_pickle=allow_pickle)
         texts = [str(s) for s in d["node_texts"]]
         label_texts = [str(s) for s in d["label_texts"]] if "label_texts" in d.files else []
     except ValueError as exc:
         raise ValueError(f"{npz_path}: text arrays are pickled object arrays; re-save them as unicode arrays "
-                         "(np.array(texts, dtype=np.str_)) - pickles are never executed here") from exc
+                         "(np.array(texts, dtype=np.str_)), or pass allow_pickle=True for a file you trust") from exc
     x = torch.tensor(d["node_features"], dtype=torch.float)
     edge_index = torch.tensor(d["edges"], dtype=torch.long)
     y = torch.tensor(d["node_labels"], dtype=torch.long)

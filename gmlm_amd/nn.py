@@ -28,8 +28,24 @@ def compute_dtype(module_dtype: Optional[torch.dtype] = None) -> torch.dtype:
     if module_dtype is not None:
         return module_dtype
     if torch.is_autocast_enabled("cuda"):
+        if torch.get_autocast_dtype("cuda") == torch.float16:
+            _warn_fp16_once()
         return torch.bfloat16
     return torch.float32
+
+
+_FP16_WARNED = False
+
+
+def _warn_fp16_once() -> None:
+    """The reference's ``torch.amp.autocast('cuda')`` defaults to fp16; these kernels compute the reduced-precision
+    path in bf16 (same operand width, 3 fewer mantissa bits, no loss scaling needed).  Said once, not silently."""
+    global _FP16_WARNED
+    if not _FP16_WARNED:
+        _FP16_WARNED = True
+        import warnings
+        warnings.warn("gmlm_amd: fp16 autocast is executed with bf16 operands (the HIP kernels' reduced precision); "
+                      "use torch.amp.autocast('cuda', dtype=torch.bfloat16) to make that explicit", stacklevel=3)
 
 
 def _glorot(t: torch.Tensor) -> None:

@@ -22,7 +22,7 @@ def _build(cfg, dev):
     return build_model(cfg, dev)
 
 
-def _worker(rank, world, port, out_dir, ring=False):
+def _worker(rank, world, port, out_dir, ring=False, shards=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -59,7 +59,15 @@ def _worker(rank, world, port, out_dir, ring=False):
         ref_model = _build(cfg, dev).train()
         ref_logits, ref_grads = run(ref_model, 0, n, None)
         model = _build(cfg, dev).train()
-        part = attach_partition(model, ei, n, dev)
+        if shards:                                              # partitioned offline into shard files; each rank reads only its own
+            from gmlm_amd.dist import write_partition_files
+            pdir = os.path.join(out_dir, "parts")
+            if rank == 0:
+                write_partition_files(ei, n, world, pdir)
+            dist.barrier()
+            part = attach_partition(model, None, n, dev, partition_dir=pdir)
+        else:
+            part = attach_partition(model, ei, n, dev)
         part.use_ring = ring                                    # K|V blocks travel rank to rank instead of the all-gather
         lo, hi = part.plan.lo, part.plan.hi
         logits, grads = run(model, lo, hi, part)
@@ -74,12 +82,13 @@ def _worker(rank, world, port, out_dir, ring=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("ring", [False, True])
-def test_partitioned_model_matches_single_gpu(tmp_path, ring):
+@pytest.mark.parametrize("ring,shards", [(False, False), (True, False), (False, True)])
+def test_partitioned_model_matches_single_gpu(tmp_path, ring, shards):
     """Halo exchange with the deferred wait (root GEMM under the all-to-all), GraphNorm all-reduce, K|V all-gather
-    or ring exchange through the HIP attention kernels: partitioned logits / gradients == single GPU."""
-    port = 33000 + (os.getpid() % 2000) + (7 if ring else 0)
-    mp.spawn(_worker, args=(2, port, str(tmp_path), ring), nprocs=2, join=True)
+    or ring exchange through the HIP attention kernels: partitioned logits / gradients == single GPU.  shards: the
+    partition comes from part-RRRRR-of-WWWWW.npz files instead of the replicated edge list."""
+    port = 33000 + (os.getpid() % 2000) + (7 if ring else 0) + (13 if shards else 0)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), ring, shards), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
 
 

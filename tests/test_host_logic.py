@@ -1,6 +1,7 @@
 """CPU tests of host-side logic that needs no GPU: NT-Xent restatement vs the golden value produced by
 main.nt_xent_loss, the .npz reader's layout / split, optimizer grouping helper."""
 import numpy as np
+import pytest
 import torch
 
 from helpers import load_golden, t
@@ -36,3 +37,14 @@ def test_npz_reader_layout_and_split(tmp_path):
     assert not bool((data.train_mask & data.val_mask).any())
     data2, _, _ = load_npz_dataset(str(path))
     assert bool(data2.test_mask.all()) and not bool(data2.train_mask.any())
+    # object-dtype text arrays (what main.py:782's allow_pickle=True implies real files hold): refused by default, read
+    # when the caller opts in for a file it wrote itself (this one)
+    obj = tmp_path / "toy_obj.npz"
+    np.savez(obj, node_features=rng.randn(n, 7).astype(np.float32), edges=rng.randint(0, n, (2, 120)),
+             node_labels=rng.randint(0, 3, n), node_texts=np.array([f"text {i}" for i in range(n)], dtype=object),
+             label_texts=np.array(["a", "b", "c"], dtype=object), train_masks=np.zeros(n, bool), val_masks=np.zeros(n, bool),
+             test_masks=np.ones(n, bool))
+    with pytest.raises(ValueError, match="allow_pickle"):
+        load_npz_dataset(str(obj))
+    data3, _, _ = load_npz_dataset(str(obj), allow_pickle=True)
+    assert data3.node_texts == data2.node_texts and data3.label_texts == ["a", "b", "c"]
