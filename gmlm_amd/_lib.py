@@ -37,26 +37,26 @@ SIGNATURES = {
     "gmlm_colstats_workspace_bytes": (_sz, [_i64, _i64]),
     "gmlm_colstats": (C.c_int, [_p, _i32, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "gmlm_graphnorm_finalize": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _f32, _p, _p, _p]),
-    "gmlm_graphnorm_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _i32, _p]),
-    "gmlm_graphnorm_bwd_stats": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _sz, _p]),
-    "gmlm_graphnorm_bwd_apply": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _u64,
+    "gmlm_graphnorm_apply": (C.c_int, [_p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _i32, _p]),
+    "gmlm_graphnorm_bwd_stats": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _p, _sz, _p]),
+    "gmlm_graphnorm_bwd_apply": (C.c_int, [_p, _i32, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _f32, _u64, _p,
                                            _p, _p, _p, _p, _p]),
-    "gmlm_bias_res_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f32, _i32, _f32, _u64, _p, _p, _p, _i32, _p]),
+    "gmlm_bias_res_layernorm_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _f32, _i32, _f32, _u64, _p, _p, _p, _p, _i32, _p]),
     "gmlm_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i64]),
-    "gmlm_bias_res_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _p, _p,
+    "gmlm_bias_res_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _p, _p, _p,
                                               _p, _i32, _p, _sz, _p]),
-    "gmlm_attention_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64,
+    "gmlm_attention_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _p,
                                      _p, _p, _i32, _p, _i64, _p]),
     "gmlm_attention_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "gmlm_attention_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32,
-                                     _f32, _u64, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p, _sz, _p]),
+                                     _f32, _u64, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p, _sz, _p]),
     "gmlm_meanpool_scatter_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i32, _p, _p]),
     "gmlm_meanpool_scatter_bwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i32, _p, _p]),
     "gmlm_softmask_blend_fwd": (C.c_int, [_p, _p, _p, _f32, _i64, _i64, _p, _i64, _i32, _p]),
     "gmlm_softmask_blend_bwd": (C.c_int, [_p, _i64, _p, _f32, _i64, _i64, _p, _p, _sz, _p]),
-    "gmlm_bias_gelu_fwd": (C.c_int, [_p, _p, _i64, _i64, _f32, _u64, _p, _i32, _p]),
+    "gmlm_bias_gelu_fwd": (C.c_int, [_p, _p, _i64, _i64, _f32, _u64, _p, _p, _i32, _p]),
     "gmlm_bias_gelu_bwd_workspace_bytes": (_sz, [_i64, _i64, _i32]),
-    "gmlm_bias_gelu_bwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _u64, _p, _p, _i32, _p, _sz, _p]),
+    "gmlm_bias_gelu_bwd": (C.c_int, [_p, _p, _p, _i64, _i64, _f32, _u64, _p, _p, _p, _i32, _p, _sz, _p]),
 }
 
 

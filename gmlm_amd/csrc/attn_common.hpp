@@ -24,6 +24,7 @@ struct AttnParams {
   uint32_t drop_thresh;   // attention-probability dropout: 8-bit threshold, P(drop) = drop_thresh / 256 (0 = off)
   float keep_scale;
   uint64_t seed;
+  const uint64_t* seed_dev;   // optional device-resident counter added to seed (hipGraph replays; see SeedArg in common.hpp)
   uint32_t grid_q, grid_pairs;   // pipelined forward: 1-D grid of grid_q query blocks x grid_pairs (batch, head) pairs
 };
 
@@ -214,6 +215,7 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {   // one multiply ro
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15;
   return x;
 }
+__device__ __forceinline__ uint64_t attn_seed(const AttnParams& p) { return p.seed_dev ? p.seed + *p.seed_dev : p.seed; }
 __device__ __forceinline__ uint32_t drop_base(uint64_t seed, int64_t slab) {
   return ((uint32_t)seed ^ (uint32_t)(seed >> 32)) + (uint32_t)slab * kDropC3;
 }

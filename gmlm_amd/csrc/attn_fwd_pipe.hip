@@ -193,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
   float m = 0.f, l = 0.f;      // reference max (log2 domain, bf16-representable, identical in both half-waves) / this half-wave's partial row sum
-  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;   // dropout hash input of the lane's query
+  const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;   // dropout hash input of the lane's query
   const int q_odd = (int)(q_row & 1);
   // lane constants of the LDS operand reads: ABSOLUTE LDS byte addresses of the lane's spot in tile buffer 0 of the K
   // ring; everything else (buffer, V ring, row block, contraction step) is an immediate offset in the hot loop

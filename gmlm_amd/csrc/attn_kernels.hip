@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
   float m = -INFINITY, l = 0.f;              // running max / sum in the log2 domain (scores * scale * log2 e)
   const float sl2 = p.scale * kLog2e;
   // dropout hash input of this lane's query (+ 2h: the lane half's keys sit 4 further on, i.e. 2 key pairs)
-  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
+  const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
   const int q_odd = (int)(q_row & 1);
   const int ntiles = (int)((kvlen + KT - 1) / KT);
   TileRegs<T, D, KT, NT> kr, vr;
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   const float lse2 = q_ok ? p.lse[lse_base + q_row] * kLog2e : INFINITY;
   const float dl = q_ok ? p.delta[lse_base + q_row] : 0.f;
   const int kvl = (int)(kvlen < (1 << 30) ? kvlen : (1 << 30));
-  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
+  const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
   const int q_odd = (int)(q_row & 1);
   f32x16 dq[DB];
 #pragma unroll
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   const float* lse_g = p.lse + lse_base;
   const float* dl_g = p.delta + lse_base;
   const float sl2 = p.scale * kLog2e;
-  const uint32_t dk_u = drop_base(p.seed, lse_base) + (uint32_t)(key >> 1) * kDropC2 + (uint32_t)(2 * h) * kDropC1;   // + 2h: the lane half's queries sit 4 further on
+  const uint32_t dk_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(key >> 1) * kDropC2 + (uint32_t)(2 * h) * kDropC1;   // + 2h: the lane half's queries sit 4 further on
   const int k_odd = (int)(key & 1);
   f32x16 dk[DB], dv[DB];
 #pragma unroll
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
   }
   __syncthreads();
   const float sl2 = p.scale * kLog2e;
-  const uint32_t d_base = drop_base(p.seed, lse_base);
+  const uint32_t d_base = drop_base(attn_seed(p), lse_base);
   auto frag = [&](const T* tile, int row, RowFrag<T, D>& f) {          // MFMA B-operand fragment of a staged row
 #pragma unroll
     for (int s = 0; s < D / 16; ++s) f.v[s] = *reinterpret_cast<const bf16x8*>(tile + row * PITCH + 16 * s + 8 * h);
@@ -692,7 +692,7 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
     rmax = fmaxf(rmax, max16(s[kb]));
   }
   const float m = nblk > 0 ? xhalf_max(rmax) * sl2 : 0.f;    // finite when any key is valid
-  const uint32_t dq_u = drop_base(p.seed, lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
+  const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
   const int q_odd = q_row & 1;
   f32x16 o[DB];
 #pragma unroll
@@ -780,7 +780,7 @@ extern "C" void gmlm_debug_set_stamp_buffer(void* p) { g_stamp_buffer = p; }
 
 extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                                   int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                  float scale, float dropout_p, uint64_t seed, void* out, float* lse, int dtype,
+                                  float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, float* lse, int dtype,
                                   const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream) {
   int rc = attn_check("attention_fwd", b, h, lq, lk, d, dtype);
   GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_fwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
@@ -799,7 +799,7 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   const int64_t rows_q = cu_seqlens ? max_len : lq;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale;
-  p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed;
+  p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed; p.seed_dev = seed_dev;
   hipStream_t st = as_stream(stream);
 #ifdef GMLM_ATTN_STAMP
   p.delta = static_cast<float*>(g_stamp_buffer);
@@ -861,7 +861,7 @@ extern "C" size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64
 extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                                   const float* lse, const int32_t* kv_len, int64_t b, int64_t h, int64_t lq, int64_t lk,
                                   int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
-                                  float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride,
+                                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                                   int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                                   void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
   int rc = attn_check("attention_bwd", b, h, lq, lk, d, dtype);
@@ -888,7 +888,7 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.dq = dq; p.dk = dk; p.dv = dv;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
-  p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed;
+  p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed; p.seed_dev = seed_dev;
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && rows_k <= 128 && b * h >= 512) {
     // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace
     static bool attr_set = false;

@@ -113,6 +113,16 @@ __device__ __forceinline__ float wave_max(float v) {
 // 16-bit thresholds (P(drop) = th / 65536), so vector kernels pay ~1.5 integer multiplies per element
 // instead of three 64-bit ones.  The same (seed, idx) gives the same decision in forward, in the
 // checkpoint recompute and in backward, so no mask tensor is stored.
+// Dropout seed as the kernels receive it: the host's per-call-site value plus an optional DEVICE-resident counter.
+// A captured hipGraph replays its kernel arguments unchanged; with `dev` set the effective seed moves with the counter
+// (bumped once per forward replay by a kernel inside the graph), so every replay draws fresh masks while forward,
+// checkpoint recompute and backward of the same replay still agree.  dev == nullptr: the plain host seed.
+struct SeedArg {
+  uint64_t v;
+  const uint64_t* dev;
+  __device__ __forceinline__ uint64_t get() const { return dev ? v + *dev : v; }
+};
+
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
   uint32_t x = (uint32_t)idx * 0x9E3779B1u + (uint32_t)(idx >> 32) * 0x85EBCA77u + (uint32_t)seed;
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

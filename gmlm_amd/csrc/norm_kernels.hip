@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void graphnorm_apply_kernel(const TY* __restri
                                                                const float* __restrict__ rstd, const float* __restrict__ w,
                                                                const float* __restrict__ b, const float* __restrict__ ms,
                                                                int64_t n, int64_t f, uint32_t thresh, float keep_scale,
-                                                               uint64_t seed, TY* __restrict__ y) {
+                                                               SeedArg seed_a, TY* __restrict__ y) {
+  const uint64_t seed = seed_a.get();
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= f) return;
   const float a = w[c] * rstd[c];
@@ -69,12 +70,12 @@ struct GraphNormBwdStatsFn {
   int64_t f;
   uint32_t thresh;
   float keep_scale;
-  uint64_t seed;
+  SeedArg seed;
   __device__ void operator()(int64_t r, int64_t c, float (&v)[2]) const {
     const int64_t i = r * f + c;
     const float oh = (Store<TG>::ld(x + i) - mean[c] * ms[c]) * rstd[c];
     float gz = Store<TG>::ld(g + i);
-    if (thresh) gz *= dropout_scale(seed, (uint64_t)i, thresh, keep_scale);
+    if (thresh) gz *= dropout_scale(seed.get(), (uint64_t)i, thresh, keep_scale);
     if (ACT) gz *= gelu_grad_t<TG>(w[c] * oh + b[c]);
     v[0] = gz;
     v[1] = gz * oh;
@@ -85,8 +86,9 @@ template <typename TG, bool ACT>
 __global__ __launch_bounds__(256) void graphnorm_bwd_apply_kernel(
     const TG* __restrict__ g, const TG* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ ms, const float* __restrict__ gs,
-    int64_t n, int64_t n_total, int64_t f, uint32_t thresh, float keep_scale, uint64_t seed, TG* __restrict__ dx,
+    int64_t n, int64_t n_total, int64_t f, uint32_t thresh, float keep_scale, SeedArg seed_a, TG* __restrict__ dx,
     float* __restrict__ dw, float* __restrict__ db, float* __restrict__ dms) {
+  const uint64_t seed = seed_a.get();
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= f) return;
   const float inv_n = 1.f / (float)n_total;
@@ -144,8 +146,9 @@ template <typename T, int CH, int LPR, bool ACT>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                       const T* __restrict__ res, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int64_t rows, int f, float eps,
-                                                      uint32_t thresh, float keep_scale, uint64_t seed, T* __restrict__ y,
+                                                      uint32_t thresh, float keep_scale, SeedArg seed_a, T* __restrict__ y,
                                                       float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const uint64_t seed = seed_a.get();
   constexpr int V = Store<T>::kVec, RPW = 64 / LPR;
   const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR;
   const int nch = f / V;
@@ -229,8 +232,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                       const float* __restrict__ bias, const T* __restrict__ res,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                      int64_t rows, int f, uint32_t thresh, float keep_scale, uint64_t seed,
+                                                      int64_t rows, int f, uint32_t thresh, float keep_scale, SeedArg seed_a,
                                                       T* __restrict__ dx, T* __restrict__ dres, float* __restrict__ partial) {
+  const uint64_t seed = seed_a.get();
   constexpr int V = Store<T>::kVec, RPW = 64 / LPR;
   static_assert(CH * V <= 32, "keep bits of one row slice must fit one word");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [4 waves][3 * f]
@@ -442,7 +446,8 @@ static inline dim3 col_stream_grid(int64_t n, int64_t f) {
 
 extern "C" int gmlm_graphnorm_apply(const void* x, const float* mean, const float* rstd, const float* weight,
                                     const float* bias, const float* mean_scale, int64_t n, int64_t f, int act,
-                                    float dropout_p, uint64_t seed, void* y, int dtype, gmlm_stream_t stream) {
+                                    float dropout_p, uint64_t seed_host, const uint64_t* seed_dev, void* y, int dtype, gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   GMLM_REQUIRE(n >= 0 && f > 0, "graphnorm_apply: bad sizes");
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "graphnorm_apply: dropout_p must be in [0,1)");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_apply: unsupported dtype");
@@ -462,8 +467,9 @@ extern "C" int gmlm_graphnorm_apply(const void* x, const float* mean, const floa
 
 extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                                         const float* weight, const float* bias, const float* mean_scale, int64_t n,
-                                        int64_t f, int act, float dropout_p, uint64_t seed, float* gs, void* workspace,
+                                        int64_t f, int act, float dropout_p, uint64_t seed_host, const uint64_t* seed_dev, float* gs, void* workspace,
                                         size_t workspace_bytes, gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   GMLM_REQUIRE(n >= 0 && f > 0 && gs, "graphnorm_bwd_stats: bad arguments");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_bwd_stats: unsupported dtype");
   GMLM_REQUIRE(n == 0 || (g && x && mean && rstd && weight && bias && mean_scale), "graphnorm_bwd_stats: null pointer");
@@ -478,8 +484,9 @@ extern "C" int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const void* x,
 
 extern "C" int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                                         const float* weight, const float* bias, const float* mean_scale, const float* gs,
-                                        int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed,
+                                        int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed_host, const uint64_t* seed_dev,
                                         void* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   GMLM_REQUIRE(n >= 0 && n_total >= n && n_total > 0 && f > 0 && gs, "graphnorm_bwd_apply: bad arguments");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "graphnorm_bwd_apply: unsupported dtype");
   GMLM_REQUIRE(mean && rstd && weight && bias && mean_scale && (n == 0 || (g && x && dx)), "graphnorm_bwd_apply: null pointer");
@@ -507,8 +514,9 @@ static int ln_check(const char* who, int64_t rows, int64_t f, int dtype, float d
 
 extern "C" int gmlm_bias_res_layernorm_fwd(const void* x, const float* bias, const void* residual, const float* gamma,
                                            const float* beta, int64_t rows, int64_t f, float eps, int act, float dropout_p,
-                                           uint64_t seed, void* y, float* mean, float* rstd, int dtype,
+                                           uint64_t seed_host, const uint64_t* seed_dev, void* y, float* mean, float* rstd, int dtype,
                                            gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   int rc = ln_check("bias_res_layernorm_fwd", rows, f, dtype, dropout_p);
   if (rc != GMLM_OK) return rc;
   if (rows == 0) return GMLM_OK;
@@ -536,9 +544,10 @@ extern "C" size_t gmlm_layernorm_bwd_workspace_bytes(int64_t rows, int64_t f) {
 
 extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias, const void* residual,
                                            const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                           int64_t rows, int64_t f, int act, float dropout_p, uint64_t seed, void* dx,
+                                           int64_t rows, int64_t f, int act, float dropout_p, uint64_t seed_host, const uint64_t* seed_dev, void* dx,
                                            void* dresidual, float* dgamma, float* dbeta, float* dbias, int dtype,
                                            void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   int rc = ln_check("bias_res_layernorm_bwd", rows, f, dtype, dropout_p);
   if (rc != GMLM_OK) return rc;
   hipStream_t st = as_stream(stream);

@@ -66,7 +66,8 @@ struct SoftmaskBwdFn {
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias,
                                                              int64_t rows, int64_t f, uint32_t thresh, float keep_scale,
-                                                             uint64_t seed, T* __restrict__ y) {
+                                                             SeedArg seed_a, T* __restrict__ y) {
+  const uint64_t seed = seed_a.get();
   constexpr int V = Store<T>::kVec;
   const int64_t nch = f / V;
   const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,8 +102,9 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
 template <typename T, bool DROP>
 __global__ __launch_bounds__(256) void bias_gelu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                              const float* __restrict__ bias, int64_t rows, int64_t f,
-                                                             uint32_t thresh, float keep_scale, uint64_t seed,
+                                                             uint32_t thresh, float keep_scale, SeedArg seed_a,
                                                              T* __restrict__ dx, float* __restrict__ dbias_partial) {
+  const uint64_t seed = seed_a.get();
   constexpr int V = Store<T>::kVec;
   const int64_t nch = f / V;
   const int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,8 +241,9 @@ static int bg_check(const char* who, int64_t rows, int64_t f, int dtype, float p
   return GMLM_OK;
 }
 
-extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed,
+extern "C" int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed_host, const uint64_t* seed_dev,
                                   void* y, int dtype, gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   int rc = bg_check("bias_gelu_fwd", rows, f, dtype, dropout_p);
   if (rc != GMLM_OK) return rc;
   if (rows == 0) return GMLM_OK;
@@ -264,8 +267,9 @@ extern "C" size_t gmlm_bias_gelu_bwd_workspace_bytes(int64_t rows, int64_t f, in
 }
 
 extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
-                                  uint64_t seed, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
+                                  uint64_t seed_host, const uint64_t* seed_dev, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
                                   gmlm_stream_t stream) {
+  const SeedArg seed{seed_host, seed_dev};
   int rc = bg_check("bias_gelu_bwd", rows, f, dtype, dropout_p);
   if (rc != GMLM_OK) return rc;
   hipStream_t st = as_stream(stream);

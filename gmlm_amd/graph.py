@@ -69,6 +69,16 @@ class RelCSR:
     def r_active(self) -> int:
         return len(self.active_relations)
 
+    @property
+    def active_index(self) -> torch.Tensor:
+        """``active_relations`` as a device index tensor, made once per graph (indexing with the Python list would build
+        it from host memory on every call: a host-to-device copy per layer, and not capturable in a hipGraph)."""
+        idx = self.__dict__.get("_active_index")
+        if idx is None:
+            idx = torch.tensor(self.active_relations, dtype=torch.long, device=self.rowptr.device)
+            self.__dict__["_active_index"] = idx
+        return idx
+
 
 def _segment_sort(node, rel, remap, r_active, num_segments):
     e = node.numel()

@@ -1,0 +1,102 @@
+"""hipGraph capture of the static-shape parts of a ``GraphTextLM`` step (launch-bound small configurations).
+
+A full-batch step on a fixed graph launches the same GNN kernels (4 x RGCN block + multi-scale fusion: main.py:250-320) and
+the same head kernels (2 x CrossAttention + fusion MLP + classifier: main.py:360-372) with the same shapes every step; on
+Cornell / Chameleon-size graphs those are a few hundred launches of 3-30 us each and the step is bound by the host's launch
+rate, not by the GPU.  ``capture(model, x_sample, edge_index)`` records both regions (forward AND backward) once with
+``torch.cuda.make_graphed_callables`` — the ctypes launches of libgmlm_hip go to the capturing stream like any other kernel —
+and ``model.forward`` replays them.  The text encoder in between stays eager: its packed token count changes with the
+active-node mask of every step.
+
+Dropout under replay: a captured kernel argument is a constant, so the host seeds drawn at capture time would repeat the same
+masks forever.  Every dropout kernel therefore takes ``(seed, seed_dev)`` and uses ``seed + *seed_dev`` (include/gmlm_hip.h);
+the capture points ``seed_dev`` at a device counter that the FIRST kernel of the GNN forward graph increments.  Forward,
+backward (and a checkpoint recompute) of one replay read the same counter value, the next replay a new one.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _Region(nn.Module):
+    """One capturable region: a callable over tensors + the parameters it touches (shared with the model, so the captured
+    backward accumulates into the model's own ``.grad``)."""
+
+    def __init__(self, fn, params, counter: torch.Tensor, bump: bool):
+        super().__init__()
+        self._fn = fn
+        self.params = nn.ParameterList(params)
+        self._counter = counter
+        self._bump = bump
+
+    def forward(self, *args):
+        prev = ops.SEED_DEVICE
+        ops.SEED_DEVICE = self._counter            # baked into the captured kernels' arguments as a pointer
+        try:
+            if self._bump:
+                self._counter.add_(1)              # captured: every forward replay moves the seed
+            return self._fn(*args)
+        finally:
+            ops.SEED_DEVICE = prev
+
+
+def _touched_params(model: nn.Module, run) -> list:
+    """Parameters that receive a gradient from ``run()`` (one eager forward + backward)."""
+    saved = {n: p.grad for n, p in model.named_parameters()}
+    for p in model.parameters():
+        p.grad = None
+    run()
+    used = [p for p in model.parameters() if p.grad is not None]
+    for n, p in model.named_parameters():
+        p.grad = saved[n]
+    return used
+
+
+class GraphedStep:
+    """Holds the two captured regions of one (model, graph) pair.  ``gnn(xm)`` -> fp32 [N, P] graph embeddings,
+    ``head(gnn_embeds, plm_embeds)`` -> logits; both are autograd-aware graph replays."""
+
+    def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None):
+        if model.dist is not None:
+            raise ValueError("hipGraph capture is single-GPU: collectives of the node partition are not captured")
+        if not model.training:
+            raise ValueError("capture in training mode (evaluation steps are not launch-bound enough to matter)")
+        dev = xm_sample.device
+        self.key = (tuple(xm_sample.shape), xm_sample.dtype, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+        self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        model.graph(edge_index, xm_sample.size(0), edge_type).active_index    # CSR build (sort, host syncs) happens before capture
+        p_dim = model.plm_encoder.config.hidden_size
+        n = xm_sample.size(0)
+
+        def gnn_fn(xm):
+            return model.get_graph_embeddings(xm, edge_index, edge_type)
+
+        def head_fn(g, t):
+            return model.head(g, t)
+
+        xs = xm_sample.detach().clone().requires_grad_(True)
+        gs = torch.randn(n, p_dim, device=dev).requires_grad_(True)
+        ts = torch.randn(n, p_dim, device=dev).requires_grad_(True)
+        gnn_params = _touched_params(model, lambda: gnn_fn(xs).sum().backward())
+        head_params = _touched_params(model, lambda: head_fn(gs, ts).sum().backward())
+        xs.grad = gs.grad = ts.grad = None
+        regions = (_Region(gnn_fn, gnn_params, self.counter, True), _Region(head_fn, head_params, self.counter, False))
+        self.gnn, self.head = torch.cuda.make_graphed_callables(regions, ((xs,), (gs, ts)), num_warmup_iters=2)
+
+    def matches(self, xm: torch.Tensor, edge_index: torch.Tensor) -> bool:
+        return self.key == (tuple(xm.shape), xm.dtype, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
+
+
+def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None) -> GraphedStep:
+    """Record the GNN and head regions for this (soft-masked input shape, graph) and attach them to ``model``:
+    ``model.forward`` replays them whenever it is called in training mode with an input of the same shape / dtype and the
+    same ``edge_index`` tensor; any other call runs eagerly.  ``model.release_hip_graphs()`` drops the recording."""
+    model._graphed = None
+    g = GraphedStep(model, xm_sample, edge_index, edge_type)
+    model._graphed = g
+    return g

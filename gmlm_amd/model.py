@@ -97,6 +97,7 @@ class GraphTextLM(nn.Module):
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
+        self._graphed = None      # gmlm_amd.graphs.GraphedStep: hipGraph recording of the GNN + head regions (capture_hip_graphs)
 
     # ------------------------------------------------------------------------------------------
     def _cd(self) -> torch.dtype:
@@ -256,10 +257,24 @@ class GraphTextLM(nn.Module):
         # the per-step compute-dtype copy of the PLM weights does not depend on the mask: its host-side set-up
         # (0.6 ms) runs here, under device work that is still queued, not between the GNN and the PLM launches
         weights = bert.prepare_weights(self.plm_encoder, self._cd())
-        gnn_embeds = self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)      # fp32 [N, P]
+        g = self._graphed
+        replay = (g is not None and self.training and torch.is_grad_enabled() and edge_type is None and self.dist is None
+                  and g.matches(gnn_input_features, edge_index))
+        gnn_embeds = g.gnn(gnn_input_features) if replay else \
+            self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)               # fp32 [N, P]
         tokens = self.tokenize(all_node_texts)
         plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)   # fp32 [N, P]
-        return self.head(gnn_embeds, plm_embeds)
+        return g.head(gnn_embeds, plm_embeds) if replay else self.head(gnn_embeds, plm_embeds)
+
+    def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor):
+        """Record the static-shape regions of the training step (GNN blocks + fusion; cross-attention + head) as hipGraphs
+        for THIS input shape and ``edge_index`` tensor; ``forward`` then replays them (training mode, same shape, same
+        edge tensor) and runs eagerly otherwise.  For the launch-bound small configurations (gmlm_amd/graphs.py)."""
+        from . import graphs
+        return graphs.capture(self, gnn_input_sample, edge_index)
+
+    def release_hip_graphs(self):
+        self._graphed = None
 
     def head(self, gnn_embeds, plm_embeds):
         """main.py:360-372."""

@@ -130,7 +130,7 @@ class RGCNConv(nn.Module):
         """[R_a * (in + pad), out]: W_r = sum_b comp[r, b] weight[b] for the relations that occur.
         ``reducer`` (node-partitioned run): all-reduces d(W_r); ``weight``/``comp`` gradients then come out
         already summed over ranks and are flagged so the bucketed gradient all-reduce skips them."""
-        comp = self.comp[csr.active_relations]                               # [R_a, B]
+        comp = self.comp.index_select(0, csr.active_index)                   # [R_a, B]
         w = _BasisCompose.apply(comp, self.weight.view(self.num_bases, -1), reducer)
         self.weight._gmlm_grad_reduced = self.comp._gmlm_grad_reduced = reducer is not None
         w = w.view(len(csr.active_relations), self.in_channels, self.out_channels)

@@ -108,6 +108,15 @@ def spmm_algorithmic_bytes(num_edges, num_segments, out_rows, f, elem, edge_w=Fa
     return float(num_edges * (f * elem + 4 + (4 if edge_w else 0)) + (num_segments + 1) * 4 + out_rows * f * elem)
 
 
+SEED_DEVICE: Optional[torch.Tensor] = None   # optional int64[1] device counter added to every dropout seed (see graphs.py)
+
+
+def _sd():
+    """Device pointer of the seed counter (None = plain host seeds).  Kernels add *ptr to the host seed when they run, so a
+    captured hipGraph draws fresh dropout masks on every replay (the counter is bumped inside the graph)."""
+    return None if SEED_DEVICE is None else SEED_DEVICE.data_ptr()
+
+
 def draw_seed() -> int:
     """Dropout seed from torch's CPU generator: replayed by torch.utils.checkpoint (RNG state is
     preserved there), costs no device sync."""
@@ -236,8 +245,9 @@ class GraphNormAct(torch.autograd.Function):
             check(lib().gmlm_graphnorm_finalize(_ptr(stats[0]), _ptr(stats[1]), _ptr(shift), _ptr(ms), n_total, f, eps,
                                                 _ptr(mean), _ptr(rstd), st), "gmlm_graphnorm_finalize")
         y = torch.empty(n, f, dtype=out_dtype, device=dev)
+        sd = ctx.sd = _sd()
         check(lib().gmlm_graphnorm_apply(_ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms), n, f, int(act),
-                                         float(p), seed, _ptr(y), dt, st), "gmlm_graphnorm_apply")
+                                         float(p), seed, sd, _ptr(y), dt, st), "gmlm_graphnorm_apply")
         ctx.save_for_backward(z, mean, rstd, w, b, ms)
         ctx.cfg = (int(act), float(p), seed, reducer, n_total)
         return y
@@ -253,8 +263,9 @@ class GraphNormAct(torch.autograd.Function):
         dt = _dt(z)
         gs = torch.empty(2, f, dtype=torch.float32, device=dev)
         ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), dev)
+        sd = ctx.sd
         check(lib().gmlm_graphnorm_bwd_stats(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b), _ptr(ms),
-                                             n, f, act, p, seed, _ptr(gs), _ptr(ws), ws.numel(), st),
+                                             n, f, act, p, seed, sd, _ptr(gs), _ptr(ws), ws.numel(), st),
               "gmlm_graphnorm_bwd_stats")
         gs_local = gs
         if reducer is not None:
@@ -266,11 +277,11 @@ class GraphNormAct(torch.autograd.Function):
             db = torch.empty_like(dw)
             dms = torch.empty_like(dw)
             check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
-                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), _ptr(dw),
+                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, sd, _ptr(dz), _ptr(dw),
                                                  _ptr(db), _ptr(dms), st), "gmlm_graphnorm_bwd_apply")
         else:
             check(lib().gmlm_graphnorm_bwd_apply(_ptr(gy), dt, _ptr(z), _ptr(mean), _ptr(rstd), _ptr(w), _ptr(b),
-                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, _ptr(dz), None, None,
+                                                 _ptr(ms), _ptr(gs), n, n_total, f, act, p, seed, sd, _ptr(dz), None, None,
                                                  None, st), "gmlm_graphnorm_bwd_apply")
             # parameter grads: LOCAL contributions only (the gradient all-reduce sums them over ranks)
             dw, db = gs_local[1].clone(), gs_local[0].clone()
@@ -298,8 +309,9 @@ class BiasResLayerNorm(torch.autograd.Function):
         y = torch.empty_like(x2)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
+        sd = ctx.sd = _sd()
         check(lib().gmlm_bias_res_layernorm_fwd(_ptr(x2), _ptr(bf), _ptr(res2), _ptr(g), _ptr(b), rows, f, float(eps),
-                                                int(act), float(p), seed, _ptr(y), _ptr(mean), _ptr(rstd), _dt(x2), _stream()),
+                                                int(act), float(p), seed, sd, _ptr(y), _ptr(mean), _ptr(rstd), _dt(x2), _stream()),
               "gmlm_bias_res_layernorm_fwd")
         ctx.save_for_backward(x2, res2, bf, g, b, mean, rstd)
         ctx.cfg = (int(act), float(p), seed, shape, bias is not None, residual is not None)
@@ -317,8 +329,9 @@ class BiasResLayerNorm(torch.autograd.Function):
         dbeta = torch.empty_like(dg)
         dbias = torch.empty_like(dg) if has_bias else None
         ws = _ws(lib().gmlm_layernorm_bwd_workspace_bytes(rows, f), x2.device)
+        sd = ctx.sd
         check(lib().gmlm_bias_res_layernorm_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), _ptr(res2), _ptr(g), _ptr(b), _ptr(mean),
-                                                _ptr(rstd), rows, f, act, p, seed, _ptr(dx), _ptr(dres), _ptr(dg),
+                                                _ptr(rstd), rows, f, act, p, seed, sd, _ptr(dx), _ptr(dres), _ptr(dg),
                                                 _ptr(dbeta), _ptr(dbias), _dt(x2), _ptr(ws), ws.numel(), _stream()),
               "gmlm_bias_res_layernorm_bwd")
         return (dx.view(shape), dbias, None if dres is None else dres.view(shape), dg, dbeta, None, None, None, None)
@@ -358,8 +371,9 @@ class Attention(torch.autograd.Function):
         out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
         lse = torch.empty(b, h, lq, dtype=torch.float32, device=q.device)
         with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * lq * lk * d):
+            sd = ctx.sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
-                                           float(p), seed, _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
+                                           float(p), seed, sd, _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
         ctx.save_for_backward(q, k, v, out, lse, kv_len)
         ctx.cfg = (h, float(scale), float(p), seed)
         return out
@@ -378,8 +392,9 @@ class Attention(torch.autograd.Function):
         dv = torch.empty(b, lk, hd, dtype=q.dtype, device=q.device)
         ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, h, lq, lk, d), q.device)
         with _span("attn_bwd_d%d" % d, flops=10.0 * b * h * lq * lk * d):
+            sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
-                                           lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, _ptr(dq),
+                                           lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, sd, _ptr(dq),
                                            _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), _stream()),
                   "gmlm_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
@@ -413,8 +428,9 @@ class AttentionQKV(torch.autograd.Function):
         # packed: exact sum of len^2 when the caller knows it (host copy of the lengths), else the bound max_len * rows
         flops = 4.0 * h * d * ((float(pair_count) if pair_count else float(max_len) * l) if packed else float(b) * l * l)
         with _span("attn_fwd_d%d" % d, flops=flops):
+            sd = ctx.sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
-                                           float(p), seed, _ptr(out), _ptr(lse), _dt(qkv), _ptr(cu_seqlens), int(max_len),
+                                           float(p), seed, sd, _ptr(out), _ptr(lse), _dt(qkv), _ptr(cu_seqlens), int(max_len),
                                            _stream()), "gmlm_attention_fwd")
         ctx.save_for_backward(qkv, out, lse, kv_len, cu_seqlens)
         ctx.cfg = (h, float(scale), float(p), seed, int(max_len), b, l, flops)
@@ -433,8 +449,9 @@ class AttentionQKV(torch.autograd.Function):
         dq, dk, dv = dqkv[..., :hd], dqkv[..., hd:2 * hd], dqkv[..., 2 * hd:]
         ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(1 if cu_seqlens is not None else b, h, l, l, d), qkv.device)
         with _span("attn_bwd_d%d" % d, flops=2.5 * flops):
+            sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
-                                           l, l, d, hd3, hd3, hd3, scale, p, seed, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
+                                           l, l, d, hd3, hd3, hd3, scale, p, seed, sd, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
                                            hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _stream()),
                   "gmlm_attention_bwd")
         return dqkv, None, None, None, None, None, None, None, None
@@ -457,8 +474,9 @@ class AttentionBlock:
         out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
         lse = torch.empty(b, self.h, lq, dtype=torch.float32, device=q.device)
         with _span("attn_fwd_d%d" % d, flops=4.0 * b * self.h * lq * lk * d):
+            sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, self.h, lq, lk, d, _rows_view(q, self.h, d),
-                                           _rows_view(k, self.h, d), _rows_view(v, self.h, d), self.scale, self.p, int(seed),
+                                           _rows_view(k, self.h, d), _rows_view(v, self.h, d), self.scale, self.p, int(seed), sd,
                                            _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
         return out, lse
 
@@ -471,9 +489,10 @@ class AttentionBlock:
         ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(b, self.h, lq, lk, d), q.device)
         out, dout, lse = out.contiguous(), dout.contiguous(), lse.contiguous()
         with _span("attn_bwd_d%d" % d, flops=10.0 * b * self.h * lq * lk * d):
+            sd = _sd()
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(kv_len), b, self.h,
                                            lq, lk, d, _rows_view(q, self.h, d), _rows_view(k, self.h, d), _rows_view(v, self.h, d),
-                                           self.scale, self.p, int(seed), _ptr(dq), _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0,
+                                           self.scale, self.p, int(seed), sd, _ptr(dq), _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0,
                                            _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
         return dq, dk, dv
 
@@ -574,7 +593,8 @@ class BiasGelu(torch.autograd.Function):
         x2 = x.contiguous().view(-1, f)
         bf = None if bias is None else _f32c(bias)
         y = torch.empty_like(x2)
-        check(lib().gmlm_bias_gelu_fwd(_ptr(x2), _ptr(bf), x2.shape[0], f, float(p), seed, _ptr(y), _dt(x2), _stream()),
+        sd = ctx.sd = _sd()
+        check(lib().gmlm_bias_gelu_fwd(_ptr(x2), _ptr(bf), x2.shape[0], f, float(p), seed, sd, _ptr(y), _dt(x2), _stream()),
               "gmlm_bias_gelu_fwd")
         ctx.save_for_backward(x2, bf)
         ctx.cfg = (float(p), seed, shape, bias is not None)
@@ -589,7 +609,8 @@ class BiasGelu(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dbias = torch.empty(f, dtype=torch.float32, device=x2.device) if has_bias else None
         ws = _ws(lib().gmlm_bias_gelu_bwd_workspace_bytes(rows, f, _dt(x2)), x2.device)
-        check(lib().gmlm_bias_gelu_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), rows, f, p, seed, _ptr(dx), _ptr(dbias), _dt(x2),
+        sd = ctx.sd
+        check(lib().gmlm_bias_gelu_bwd(_ptr(gy2), _ptr(x2), _ptr(bf), rows, f, p, seed, sd, _ptr(dx), _ptr(dbias), _dt(x2),
                                        _ptr(ws), ws.numel(), _stream()), "gmlm_bias_gelu_bwd")
         return dx.view(shape), dbias, None, None
 

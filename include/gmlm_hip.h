@@ -134,20 +134,23 @@ int gmlm_colstats(const void* x, int dtype, const float* shift, int64_t n, int64
 int gmlm_graphnorm_finalize(const float* s1, const float* s2, const float* shift, const float* mean_scale,
                             int64_t n_total, int64_t f, float eps, float* mean, float* rstd, gmlm_stream_t stream);
 /* y = dropout(gelu(weight * (x - mean*ms) * rstd + bias)); y stored as `dtype`; act != 0 applies GELU.
- * dropout: keep-probability scaling 1/(1-p), mask = hash(seed, element index) (replayable). */
+ * dropout: keep-probability scaling 1/(1-p), mask = hash(seed, element index) (replayable).
+ * Every entry with a `seed` also takes `seed_dev`: NULL, or a device pointer to one uint64 that the kernel ADDS to `seed`
+ * when it runs.  A captured hipGraph replays its arguments unchanged; pointing seed_dev at a counter that the graph itself
+ * increments gives every replay fresh masks while forward / recompute / backward of one replay still agree. */
 int gmlm_graphnorm_apply(const void* x, const float* mean, const float* rstd, const float* weight,
                          const float* bias, const float* mean_scale, int64_t n, int64_t f, int act,
-                         float dropout_p, uint64_t seed, void* y, int dtype, gmlm_stream_t stream);
+                         float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* y, int dtype, gmlm_stream_t stream);
 /* backward, pass 1: column sums needed by the closed form.  g = dL/dy (dtype), x = saved pre-norm input.
  * gs[0,c] = sum_i gz[i,c], gs[1,c] = sum_i gz[i,c] * ohat[i,c]   (gz = g through dropout and GELU) */
 int gmlm_graphnorm_bwd_stats(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                              const float* weight, const float* bias, const float* mean_scale, int64_t n, int64_t f,
-                             int act, float dropout_p, uint64_t seed, float* gs /* [2, f] */,
+                             int act, float dropout_p, uint64_t seed, const uint64_t* seed_dev, float* gs /* [2, f] */,
                              void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
 /* backward, pass 2: dx (`dtype`) and parameter grads from the (all-reduced) column sums over n_total rows. */
 int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const void* x, const float* mean, const float* rstd,
                              const float* weight, const float* bias, const float* mean_scale, const float* gs,
-                             int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed,
+                             int64_t n, int64_t n_total, int64_t f, int act, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                              void* dx, float* dweight, float* dbias, float* dmean_scale, gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -159,13 +162,13 @@ int gmlm_graphnorm_bwd_apply(const void* g, int dtype, const void* x, const floa
  * ------------------------------------------------------------------------------------------- */
 int gmlm_bias_res_layernorm_fwd(const void* x, const float* bias, const void* residual, const float* gamma,
                                 const float* beta, int64_t rows, int64_t f, float eps, int act, float dropout_p,
-                                uint64_t seed, void* y, float* mean, float* rstd, int dtype, gmlm_stream_t stream);
+                                uint64_t seed, const uint64_t* seed_dev, void* y, float* mean, float* rstd, int dtype, gmlm_stream_t stream);
 /* dz (written to dx; the residual branch receives the same dz; dbias = column sum of dx through dropout)
  * partial parameter grads are reduced inside: dgamma/dbeta/dbias [f] fp32 (zero-initialised by the call). */
 size_t gmlm_layernorm_bwd_workspace_bytes(int64_t rows, int64_t f);
 int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias, const void* residual,
                                 const float* gamma, const float* beta, const float* mean, const float* rstd,
-                                int64_t rows, int64_t f, int act, float dropout_p, uint64_t seed, void* dx,
+                                int64_t rows, int64_t f, int act, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dx,
                                 void* dresidual, float* dgamma, float* dbeta, float* dbias, int dtype,
                                 void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
 
@@ -193,14 +196,14 @@ int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias
  * ------------------------------------------------------------------------------------------- */
 int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                        int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                       float scale, float dropout_p, uint64_t seed, void* out, float* lse, int dtype,
+                       float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, float* lse, int dtype,
                        const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream);
 /* packed mode: pass b = 1 (delta is [h, total_rows]) */
 size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d);
 int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                        const float* lse, const int32_t* kv_len, int64_t b, int64_t h, int64_t lq, int64_t lk,
                        int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
-                       float dropout_p, uint64_t seed, void* dq, void* dk, void* dv, int64_t dq_stride,
+                       float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                        int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                        void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
 
@@ -227,13 +230,13 @@ int gmlm_softmask_blend_bwd(const float* dout, int64_t dout_stride, const uint8_
 
 /* GELU (exact erf) + dropout elementwise with optional bias, used for BertIntermediate
  * (hf:modeling_bert.py:333-336) and classifier.1 (main.py:245): y = dropout(gelu(x + bias)). */
-int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed,
+int gmlm_bias_gelu_fwd(const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
                        void* y, int dtype, gmlm_stream_t stream);
 /* dx = dy * dropout_mask * gelu'(x + bias); dbias (nullable) [f] = column sums of dx, accumulated in fp32
  * inside the same pass (workspace: gmlm_bias_gelu_bwd_workspace_bytes). */
 size_t gmlm_bias_gelu_bwd_workspace_bytes(int64_t rows, int64_t f, int dtype);
 int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bias, int64_t rows, int64_t f, float dropout_p,
-                       uint64_t seed, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
+                       uint64_t seed, const uint64_t* seed_dev, void* dx, float* dbias, int dtype, void* workspace, size_t workspace_bytes,
                        gmlm_stream_t stream);
 
 #ifdef __cplusplus

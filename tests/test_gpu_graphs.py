@@ -1,0 +1,139 @@
+"""hipGraph capture of the GNN + head regions (gmlm_amd/graphs.py) and the device-side dropout seed it needs.
+
+* seed plumbing: every dropout kernel takes (seed, seed_dev) and must behave exactly like the plain seed ``seed + *seed_dev``
+  (forward AND backward) -- bit-exact against the same op called with that host seed;
+* replay == eager, bit for bit, with dropout off (same kernels, same order, same inputs);
+* with dropout on, consecutive replays draw different masks and stay finite."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_model import build_model, dev  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_counter(value, dev, fn):
+    from gmlm_amd import ops
+    ops.SEED_DEVICE = torch.full((1,), value, dtype=torch.int64, device=dev)
+    try:
+        return fn()
+    finally:
+        ops.SEED_DEVICE = None
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_device_seed_equals_host_seed_sum(dev, dtype):
+    from gmlm_amd import ops
+    g = torch.Generator(device=dev).manual_seed(11)
+    s0, c = 123456789, 1000003
+
+    def run_all(seed):
+        outs = []
+        x = torch.randn(300, 256, device=dev, generator=g, dtype=dtype).requires_grad_(True)
+        b = torch.randn(256, device=dev).requires_grad_(True)
+        y = ops.BiasGelu.apply(x, b, 0.3, seed)
+        y.backward(torch.ones_like(y))
+        outs += [y.detach(), x.grad.clone(), b.grad.clone()]
+        x2 = torch.randn(300, 256, device=dev, dtype=dtype).requires_grad_(True)
+        res = torch.randn(300, 256, device=dev, dtype=dtype)
+        gm, bt = torch.ones(256, device=dev, requires_grad=True), torch.zeros(256, device=dev, requires_grad=True)
+        y2 = ops.BiasResLayerNorm.apply(x2, b.detach(), res, gm, bt, 1e-5, True, 0.3, seed)
+        y2.backward(torch.ones_like(y2))
+        outs += [y2.detach(), x2.grad.clone(), gm.grad.clone()]
+        z = torch.randn(300, 256, device=dev, dtype=dtype).requires_grad_(True)
+        w, bb, ms = (torch.ones(256, device=dev, requires_grad=True), torch.zeros(256, device=dev, requires_grad=True),
+                     torch.ones(256, device=dev, requires_grad=True))
+        y3 = ops.GraphNormAct.apply(z, w, bb, ms, 1e-5, True, 0.3, seed, dtype, None, 300)
+        y3.backward(torch.ones_like(y3))
+        outs += [y3.detach(), z.grad.clone(), w.grad.clone()]
+        q, k, v = (torch.randn(2, 200, 4 * 64, device=dev, dtype=dtype).requires_grad_(True) for _ in range(3))
+        o = ops.Attention.apply(q, k, v, None, 4, 0.125, 0.2, seed)
+        o.backward(torch.ones_like(o))
+        outs += [o.detach(), q.grad.clone(), k.grad.clone(), v.grad.clone()]
+        return outs
+
+    g.manual_seed(11); torch.manual_seed(5)
+    ref = run_all(s0 + c)
+    g.manual_seed(11); torch.manual_seed(5)
+    got = _with_counter(c, dev, lambda: run_all(s0))
+    g.manual_seed(11); torch.manual_seed(5)
+    other = _with_counter(c + 1, dev, lambda: run_all(s0))
+    for i, (a, b_) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b_), f"tensor {i}: (seed, counter) differs from the plain seed seed + counter"
+    assert not torch.equal(ref[0], other[0]) and not torch.equal(ref[9], other[9])      # the counter moves the masks
+
+
+def _cfg(drop):
+    plm = dict(hidden=128, layers=2, heads=2, inter=256, max_pos=64, vocab=200)
+    return dict(n=301, e=2500, f_in=40, hc=32, c=5, plm=plm, seed=91, max_len=12)
+
+
+def _data(cfg, dev):
+    import gmlm_oracle as O
+    import gmlm_amd
+    g = torch.Generator().manual_seed(9)
+    n = cfg["n"]
+    x = torch.randn(n, cfg["f_in"], generator=g).to(dev)
+    ei = torch.randint(0, n, (2, cfg["e"]), generator=g).to(dev)
+    y = torch.randint(0, cfg["c"], (n,), generator=g).to(dev)
+    ids, am = O.synthetic_tokens(n, 12, 200, 5, 2)
+    tokens = gmlm_amd.TokenizedTexts.from_mask(ids.to(dev), am.to(dev))
+    masks = [(torch.rand(n, generator=g) < 0.5).to(dev) for _ in range(3)]
+    return x, ei, y, tokens, masks
+
+
+def _step(m, x, ei, y, tokens, mask):
+    m.zero_grad(set_to_none=True)
+    logits = m(m.soft_mask_input(x, mask, 0.7), ei, tokens, mask, plm_batch_size=64)
+    loss = F.cross_entropy(logits[mask], y[mask], label_smoothing=0.2)
+    loss.backward()
+    return logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_replay_equals_eager_without_dropout(dev, cd):
+    cfg = _cfg(0.0)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+    eager = build_model(cfg, dev, compute_dtype=cd).train()             # build_model: dropout_rate = 0
+    graphed = build_model(cfg, dev, compute_dtype=cd).train()
+    graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei)
+    for mask in masks:                                                   # the active set (hence the eager PLM part) changes per step
+        l0, g0 = _step(eager, x, ei, y, tokens, mask)
+        l1, g1 = _step(graphed, x, ei, y, tokens, mask)
+        assert torch.equal(l0, l1)
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+    graphed.eval()                                                       # evaluation falls back to the eager path
+    eager.eval()
+    with torch.no_grad():
+        a = graphed(graphed.soft_mask_input(x, masks[0], 0.7), ei, tokens, masks[0], plm_batch_size=64)
+        b = eager(eager.soft_mask_input(x, masks[0], 0.7), ei, tokens, masks[0], plm_batch_size=64)
+    assert torch.equal(a, b)
+
+
+def test_replays_draw_fresh_dropout_masks(dev):
+    import gmlm_amd
+    from test_gpu_model import hf_bert
+    from helpers import model_state_template
+    from param_recipe import recipe_state_dict
+    cfg = _cfg(0.3)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+    m = gmlm_amd.GraphTextLM(cfg["f_in"], cfg["hc"], cfg["c"], dropout_rate=0.3, plm_encoder=hf_bert(cfg["plm"]),
+                             plm_max_length=12, compute_dtype=torch.bfloat16)
+    m.load_state_dict(recipe_state_dict(model_state_template(cfg["f_in"], cfg["hc"], cfg["c"], cfg["plm"]), cfg["seed"]))
+    m = m.to(dev).train()
+    xm = m.soft_mask_input(x, masks[0], 0.7)
+    g = m.capture_hip_graphs(xm, ei)
+    c0 = int(g.counter.item())
+    e1 = g.gnn(xm).detach().clone()
+    e2 = g.gnn(xm).detach().clone()
+    assert int(g.counter.item()) == c0 + 2                              # bumped inside the graph, once per forward replay
+    assert torch.isfinite(e1).all() and torch.isfinite(e2).all() and not torch.equal(e1, e2)
+    losses = []
+    for mask in masks:
+        logits, grads = _step(m, x, ei, y, tokens, mask)
+        assert torch.isfinite(logits).all() and all(torch.isfinite(v).all() for v in grads.values())
+        losses.append(float(F.cross_entropy(logits[mask], y[mask])))
+    assert len(set(losses)) == len(losses)
