@@ -225,6 +225,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   const int kvl = (int)(kvlen < (1 << 30) ? kvlen : (1 << 30));
   const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
   const int q_odd = (int)(q_row & 1);
+  // bf16: the per-score fma / compare / select work rides in the MFMA chains (as in the pipelined forward).  Q is
+  // pre-multiplied by scale * log2 e (the SAME rounding the forward applies), and each chain starts with one extra
+  // contraction step  [1 1 m 0 ..] x [-lse_hi -lse_lo -2^100 0 ..]^T  (m = 1 for a masked key): scores leave the
+  // chain as s*scale*log2e - lse, masked keys at about -1.3e30, so P = exp2(.) with no further arithmetic; without
+  // dropout the dP chain starts from  [1 1 0 ..] x [-delta_hi -delta_lo 0 ..]^T  and dS = P * (dP - delta) is one multiply.
+  // lse / delta are split into two bf16 terms (hi + lo: relative error 2^-17).
+  constexpr bool FOLD = sizeof(T) == 2;
+  bf16x8 ones_a, ext_s, ext_dp;
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int s_ = 0; s_ < D / 16; ++s_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf.v[s_][j] = (__bf16)((float)qf.v[s_][j] * sl2);
+    const float l2 = q_ok ? lse2 : 0x1p100f;                 // a row past the sequence: probability 0 everywhere
+    const float lh = (float)(__bf16)l2, ll = (float)(__bf16)(l2 - lh);
+    const float dh = (float)(__bf16)dl, dlo = (float)(__bf16)(dl - dh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ones_a[j] = (__bf16)0.f; ext_s[j] = (__bf16)0.f; ext_dp[j] = (__bf16)0.f; }
+    if (h == 0) {
+      ones_a[0] = (__bf16)1.f; ones_a[1] = (__bf16)1.f;
+      ext_s[0] = (__bf16)(-lh); ext_s[1] = (__bf16)(-ll); ext_s[2] = (__bf16)(-0x1p100f);
+      ext_dp[0] = (__bf16)(-dh); ext_dp[1] = (__bf16)(-dlo);
+    }
+  }
   f32x16 dq[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -255,21 +279,38 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      const bool full = kv0 + (kb + 1) * 32 <= kvlen;          // block-uniform
+      if constexpr (FOLD) {
+        bf16x8 oa = ones_a;
+        if (!full) oa[2] = (h == 0 && (int)kv0 + kb * 32 + r >= kvl) ? (__bf16)1.f : (__bf16)0.f;   // A row r = key r of the block
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, ext_s, s, 0, 0, 0);
+        if (!DROP) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones_a, ext_dp, dp, 0, 0, 0);
+      }
       mma_rows<D>(ks[cur], PITCH, kb * 32, qf, s, r, h);
       mma_rows<D>(vs[cur], PITCH, kb * 32, dof, dp, r, h);
-      const bool full = kv0 + (kb + 1) * 32 <= kvlen;          // block-uniform
 #pragma unroll
       for (int i = 0; i < 16; i += 2) {
-        const int key = (int)kv0 + kb * 32 + acc_row(i, h);      // even; registers i, i+1 = keys key, key+1
-        // a masked key gets exponent -inf through a select (no branch around the exp); whole blocks skip the test;
-        // a query row past the sequence has lse = +inf, i.e. probability 0 everywhere
-        float a0 = fmaf(s[i], sl2, -lse2), a1 = fmaf(s[i + 1], sl2, -lse2);
-        if (!full) { a0 = key < kvl ? a0 : -INFINITY; a1 = key + 1 < kvl ? a1 : -INFINITY; }
-        const float p0 = fast_exp2(a0), p1 = fast_exp2(a1);
-        float m0 = 1.f, m1 = 1.f;
-        if (DROP) drop_pair_q(dq_u + ((uint32_t)(t * (KT / 2)) + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1)) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
-        s[i] = p0 * (dp[i] * m0 - dl);
-        s[i + 1] = p1 * (dp[i + 1] * m1 - dl);
+        float p0, p1;
+        if constexpr (FOLD) {
+          p0 = fast_exp2(s[i]);
+          p1 = fast_exp2(s[i + 1]);
+        } else {
+          const int key = (int)kv0 + kb * 32 + acc_row(i, h);      // even; registers i, i+1 = keys key, key+1
+          // a masked key gets exponent -inf through a select (no branch around the exp); whole blocks skip the test;
+          // a query row past the sequence has lse = +inf, i.e. probability 0 everywhere
+          float a0 = fmaf(s[i], sl2, -lse2), a1 = fmaf(s[i + 1], sl2, -lse2);
+          if (!full) { a0 = key < kvl ? a0 : -INFINITY; a1 = key + 1 < kvl ? a1 : -INFINITY; }
+          p0 = fast_exp2(a0); p1 = fast_exp2(a1);
+        }
+        if (FOLD && !DROP) {
+          s[i] = p0 * dp[i];
+          s[i + 1] = p1 * dp[i + 1];
+        } else {
+          float m0 = 1.f, m1 = 1.f;
+          if (DROP) drop_pair_q(dq_u + ((uint32_t)(t * (KT / 2)) + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1)) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
+          s[i] = p0 * (dp[i] * m0 - dl);
+          s[i + 1] = p1 * (dp[i + 1] * m1 - dl);
+        }
       }
       mma_acc<D>(ks[cur], PITCH, kb * 32, s, dq, lane);
     }
@@ -312,6 +353,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) T dos[NBUF][QT * PITCH];
   __shared__ __attribute__((aligned(16))) float lse_s[NBUF][QT];
   __shared__ __attribute__((aligned(16))) float dl_s[NBUF][QT];
+  // bf16: per query row, the A fragments of the extra contraction steps (see attn_bwd_dq_kernel): 16 elements each,
+  // [-lse_hi -lse_lo -2^100 0 x 13] and [-delta_hi -delta_lo 0 x 14]; the key side holds [1 1 masked 0 ..] in registers
+  constexpr bool FOLD = sizeof(T) == 2;
+  __shared__ __attribute__((aligned(16))) bf16_t ext_s[FOLD ? NBUF : 1][FOLD ? QT * 16 : 8];
+  __shared__ __attribute__((aligned(16))) bf16_t ext_d[FOLD ? NBUF : 1][FOLD ? QT * 16 : 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.y / p.h, hd = blockIdx.y % p.h;
   int64_t lq_, lk_, qbase, kbase, lse_base;
@@ -334,6 +380,20 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   const float sl2 = p.scale * kLog2e;
   const uint32_t dk_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(key >> 1) * kDropC2 + (uint32_t)(2 * h) * kDropC1;   // + 2h: the lane half's queries sit 4 further on
   const int k_odd = (int)(key & 1);
+  bf16x8 ones_k, ones_2;
+  if constexpr (FOLD) {
+    // K' = bf16(K * scale * log2 e) (one more bf16 rounding, the size of the one the forward applies to Q)
+#pragma unroll
+    for (int s_ = 0; s_ < D / 16; ++s_)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf.v[s_][j] = (__bf16)((float)kf.v[s_][j] * sl2);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ones_k[j] = (__bf16)0.f; ones_2[j] = (__bf16)0.f; }
+    if (h == 0) {
+      ones_k[0] = ones_2[0] = (__bf16)1.f; ones_k[1] = ones_2[1] = (__bf16)1.f;
+      ones_k[2] = key_ok ? (__bf16)0.f : (__bf16)1.f;        // this lane's key is masked: its scores get -2^100
+    }
+  }
   f32x16 dk[DB], dv[DB];
 #pragma unroll
   for (int d = 0; d < DB; ++d)
@@ -355,7 +415,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
       }
     };
     auto store_small = [&](int buf) {
-      if (tid < QT) { lse_s[buf][tid] = lr; dl_s[buf][tid] = dr; }
+      if (tid < QT) {
+        lse_s[buf][tid] = lr; dl_s[buf][tid] = dr;
+        if constexpr (FOLD) {
+          const float l2 = lr < 0x1p100f ? lr : 0x1p100f;            // +inf (row past the sequence): probability 0
+          const float lh = (float)(__bf16)l2, ll = (float)(__bf16)(l2 - lh);
+          const float dh = (float)(__bf16)dr, dlo = (float)(__bf16)(dr - dh);
+          bf16x8 es, ed, z;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { es[j] = (__bf16)0.f; ed[j] = (__bf16)0.f; z[j] = (__bf16)0.f; }
+          es[0] = (__bf16)(-lh); es[1] = (__bf16)(-ll); es[2] = (__bf16)(-0x1p100f);
+          ed[0] = (__bf16)(-dh); ed[1] = (__bf16)(-dlo);
+          *reinterpret_cast<bf16x8*>(&ext_s[buf][tid * 16]) = es;
+          *reinterpret_cast<bf16x8*>(&ext_s[buf][tid * 16 + 8]) = z;
+          *reinterpret_cast<bf16x8*>(&ext_d[buf][tid * 16]) = ed;
+          *reinterpret_cast<bf16x8*>(&ext_d[buf][tid * 16 + 8]) = z;
+        }
+      }
     };
     if (ntiles > 0) {
       qr.load(qg, p.q_stride, 0, lq_, tid);
@@ -382,8 +458,24 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
         f32x16 s, dp;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+        if constexpr (FOLD) {
+          const bf16x8 ea = *reinterpret_cast<const bf16x8*>(&ext_s[cur][(qb * 32 + r) * 16 + 8 * h]);   // A row r = query r of the block
+          s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ea, ones_k, s, 0, 0, 0);
+          if (!DROP) {
+            const bf16x8 da = *reinterpret_cast<const bf16x8*>(&ext_d[cur][(qb * 32 + r) * 16 + 8 * h]);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, ones_2, dp, 0, 0, 0);
+          }
+        }
         mma_rows<D>(qs[cur], PITCH, qb * 32, kf, s, r, h);
         mma_rows<D>(dos[cur], PITCH, qb * 32, vf, dp, r, h);
+        if constexpr (FOLD && !DROP) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float pr = fast_exp2(s[i]);
+            s[i] = pr;
+            dp[i] = pr * dp[i];
+          }
+        } else {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int q4 = qb * 32 + 8 * g4 + 4 * h;       // accumulator registers 4*g4 .. 4*g4+3 = queries q4 .. q4+3
@@ -395,8 +487,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
             const int i = 4 * g4 + j;                        // registers i, i+1 = queries q0 + q4 + j, + 1 (even, odd)
             // query rows past the sequence carry lse = +inf in LDS, masked keys select the exponent -inf: both give
             // probability exactly 0 without a branch around the exp
-            const float p0 = fast_exp2(key_ok ? fmaf(s[i], sl2, -lv[j]) : -INFINITY);
-            const float p1 = fast_exp2(key_ok ? fmaf(s[i + 1], sl2, -lv[j + 1]) : -INFINITY);
+            const float p0 = FOLD ? fast_exp2(s[i]) : fast_exp2(key_ok ? fmaf(s[i], sl2, -lv[j]) : -INFINITY);
+            const float p1 = FOLD ? fast_exp2(s[i + 1]) : fast_exp2(key_ok ? fmaf(s[i + 1], sl2, -lv[j + 1]) : -INFINITY);
             float m0 = 1.f, m1 = 1.f;
             if (DROP) drop_pair_k(dk_u + ((uint32_t)(q0 >> 1) + (uint32_t)((qb * 32 + 8 * g4 + j) >> 1)) * kDropC1, k_odd, p.drop_thresh, p.keep_scale, m0, m1);
             s[i] = p0 * m0;
@@ -404,6 +496,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
             dp[i] = p0 * (dp[i] * m0 - dv4[j]);
             dp[i + 1] = p1 * (dp[i + 1] * m1 - dv4[j + 1]);
           }
+        }
         }
         mma_acc<D>(dos[cur], PITCH, qb * 32, s, dv, lane);
         mma_acc<D>(qs[cur], PITCH, qb * 32, dp, dk, lane);
