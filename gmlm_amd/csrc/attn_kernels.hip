@@ -924,8 +924,8 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   if (dtype == GMLM_BF16 && (d == 96 || rows_q > 128)) {
     // software-pipelined LDS-DMA kernel (attn_fwd_pipe.hip): CrossAttention geometry (d = 96: +40-45 % at N = 5k-20k
     // against attn_fwd_kernel) and BERT geometry beyond 128 tokens (d = 64: +8 % at L = 512, +15 % at L = 2048).
-    // Sequences of <= 128 tokens (one query block per sequence: what the reference's tokeniser produces,
-    // main.py:340) stay on the lighter kernel below, which keeps 3 waves per SIMD and is 5-9 % faster there.
+    // Sequences of <= 128 tokens (what the reference's tokeniser produces, main.py:340) go to attn_fwd_short_kernel above
+    // when there are enough of them; this kernel measures the same there (171 vs 175 us on the bench's packed mix).
     const int nw = d == 96 ? (pick_waves(rows_q, b * h) == 8 ? 8 : 4) : 4;
     rc = attn_fwd_pipe_launch(p, (int)d, nw, rows_q, b * h, st);
     if (rc != GMLM_OK) return rc;
