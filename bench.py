@@ -447,6 +447,8 @@ def main():
     ap.add_argument("--partition-dir", default=None, help="s5: read this rank's shard (gmlm_amd.dist.write_partition_files) instead of planning from the edge list")
     ap.add_argument("--plm-ckpt", action="store_true", help="HF-style gradient checkpointing of the text encoder (reference: main.py:217-218)")
     ap.add_argument("--no-fp32-leg", action="store_true")
+    ap.add_argument("--no-gemm-tuning", action="store_true", help="library default GEMM algorithms instead of the looked-up picks (gmlm_amd/tuning.py)")
+    ap.add_argument("--gemm-tune", default=None, metavar="CSV", help="time the library's GEMM candidates for every shape of this run and write the picks to CSV (offline step)")
     ap.add_argument("--hip-graph", action="store_true", help="replay the static-shape regions (GNN blocks, cross-attention + head) from hipGraphs: for the launch-bound small workloads")
     ap.add_argument("--ring", action="store_true", help="N > 1: CrossAttention through the ring K|V exchange instead of the K|V all-gather")
     ap.add_argument("--no-ring", action="store_true")
@@ -472,8 +474,13 @@ def main():
     args = ap.parse_args()
 
     import gmlm_amd
-    from gmlm_amd import ops
+    from gmlm_amd import ops, tuning
 
+    gemm_tuning = False
+    if args.gemm_tune:
+        gemm_tuning = tuning.enable_gemm_tuning(args.gemm_tune, tune=True)
+    elif not args.no_gemm_tuning:
+        gemm_tuning = tuning.enable_gemm_tuning()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -575,7 +582,10 @@ def main():
                                f"hidden_channels={args.hc}, BERT geometry {args.plm_hidden}x{args.plm_layers}, "
                                f"{n_active_total} active text nodes, 16..{args.max_len} tokens, plm_batch_size={args.plm_batch}",
                    "global_nodes": data["n"], "parallelism": f"1-D node partition x{world}" if distributed else "single GPU",
-                   "hip_graph": bool(args.hip_graph), "loss": round(float(loss.detach()), 5)},
+                   "hip_graph": bool(args.hip_graph),
+                   "gemm_algorithms": ("library picks from gmlm_amd/tunable/gfx950.csv (TunableOp lookup)" if gemm_tuning and not args.gemm_tune
+                                       else "tuned in this run" if gemm_tuning else "library default heuristic"),
+                   "loss": round(float(loss.detach()), 5)},
     }
     if rank == 0 and timer is not None:
         summ = timer.summary()

@@ -1,0 +1,38 @@
+"""Library-GEMM algorithm selection for the dense projections (hipBLASLt / rocBLAS through PyTorch's TunableOp).
+
+60 % of the headline step is plain library GEMMs (BERT projections at T ~ 9e4 tokens, K = 768 / 3072; RGCN H W_cat): the
+library's default heuristic is within 0-15 % of its own best kernel per shape.  ``enable_gemm_tuning`` switches TunableOp on:
+* ``tune=False`` (default): only LOOK UP a results file (``gmlm_amd/tunable/gfx950.csv`` ships the picks for the bench
+  workloads; the file carries validators for the PyTorch / HIP / hipBLASLt / rocBLAS versions and the GPU arch, and is
+  ignored — default algorithms — when they do not match);
+* ``tune=True``: time every candidate the first time a shape is seen and write the results file (tens of seconds for a
+  BERT-base step; done once, offline).
+The numerics are those of the library kernels either way (bf16 operands, fp32 accumulation)."""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950.csv")
+
+
+def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tuning_ms: int = 200) -> bool:
+    """-> True when TunableOp is active with ``path`` (existing file, or tuning requested)."""
+    path = path or DEFAULT_FILE
+    if not tune and not os.path.exists(path):
+        return False
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.tuning_enable(bool(tune))
+    t.set_filename(path, insert_device_ordinal=False)
+    if tune:
+        t.set_max_tuning_duration(int(max_tuning_ms))              # the results file is written by TunableOp as shapes are tuned / at exit
+    elif os.path.exists(path):
+        t.read_file(path)
+    return True
+
+
+def disable_gemm_tuning() -> None:
+    torch.cuda.tunable.enable(False)
