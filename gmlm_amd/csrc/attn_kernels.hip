@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 template <typename T, int D, int NW, bool DROP>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(AttnParams p) {
   constexpr bool DBUF = sizeof(T) == 2;
-  constexpr int KT = DBUF ? 64 : 32, KB = KT / 32, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
+  constexpr int KT = DBUF ? (NW == 8 ? 128 : 64) : 32;   // 8-wave blocks own the CU (202 VGPRs): 128-key tiles halve their barriers (-4 %)
+  constexpr int KB = KT / 32, NT = NW * 64, PITCH = D + Pad<T>::v, DB = D / 32, NBUF = DBUF ? 2 : 1;
   __shared__ __attribute__((aligned(16))) T ks[NBUF][KT * PITCH];
   __shared__ __attribute__((aligned(16))) T vs[NBUF][KT * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
