@@ -1043,12 +1043,21 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       // short sequences (the reference tokenises to <= 128 tokens): all query rows staged behind one barrier
       if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 128><<<gk, 256, 0, st>>>(p); }
       else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 4, false, 128><<<gk, 256, 0, st>>>(p); }
+    } else if (dtype == GMLM_BF16) {
+      // 64 query rows per barrier (two 32-row blocks), double-buffered: -8 % at L = 512 against 32-row tiles
+      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 64><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 64><<<gk, 256, 0, st>>>(p); }
+      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 4, true, 64><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 4, false, 64><<<gk, 256, 0, st>>>(p); }
     } else {
       GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
     }
   } else {
     dim3 gk((unsigned)cdiv(rows_k, 64), (unsigned)(b * h));
-    GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
+    if (dtype == GMLM_BF16 && rows_q > 128) {      // 64-row tiles here too: -11 % at N = 5,201
+      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 2, false, 64><<<gk, 128, 0, st>>>(p); }
+      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 2, false, 64><<<gk, 128, 0, st>>>(p); }
+    } else {
+      GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
+    }
   }
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
