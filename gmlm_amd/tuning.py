@@ -26,11 +26,15 @@ def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tunin
     t = torch.cuda.tunable
     t.enable(True)
     t.tuning_enable(bool(tune))
-    t.set_filename(path, insert_device_ordinal=False)
     if tune:
+        t.set_filename(path, insert_device_ordinal=False)
         t.set_max_tuning_duration(int(max_tuning_ms))              # the results file is written by TunableOp as shapes are tuned / at exit
-    elif os.path.exists(path):
+    else:
         t.read_file(path)
+        # look-up only: whatever TunableOp may still want to write goes to a scratch file of this process, never to the
+        # shipped picks (several ranks share them)
+        import tempfile
+        t.set_filename(os.path.join(tempfile.gettempdir(), "gmlm_tunable_%d.csv" % os.getpid()), insert_device_ordinal=False)
     return True
 
 
