@@ -449,6 +449,8 @@ def main():
     ap.add_argument("--no-fp32-leg", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library default GEMM algorithms instead of the looked-up picks (gmlm_amd/tuning.py)")
     ap.add_argument("--gemm-tune", default=None, metavar="CSV", help="time the library's GEMM candidates for every shape of this run and write the picks to CSV (offline step)")
+    ap.add_argument("--gemm-tune-rotate", type=int, default=None, metavar="MB", help="with --gemm-tune: rotate the operands through a buffer of this size (cold-cache timing)")
+    ap.add_argument("--gemm-picks", default=None, metavar="CSV", help="look up this results file instead of gmlm_amd/tunable/gfx950.csv")
     ap.add_argument("--hip-graph", action="store_true", help="replay the static-shape regions (GNN blocks, cross-attention + head) from hipGraphs: for the launch-bound small workloads")
     ap.add_argument("--ring", action="store_true", help="N > 1: CrossAttention through the ring K|V exchange instead of the K|V all-gather")
     ap.add_argument("--no-ring", action="store_true")
@@ -478,9 +480,9 @@ def main():
 
     gemm_tuning = False
     if args.gemm_tune:
-        gemm_tuning = tuning.enable_gemm_tuning(args.gemm_tune, tune=True)
+        gemm_tuning = tuning.enable_gemm_tuning(args.gemm_tune, tune=True, rotating_buffer_mb=args.gemm_tune_rotate)
     elif not args.no_gemm_tuning:
-        gemm_tuning = tuning.enable_gemm_tuning()
+        gemm_tuning = tuning.enable_gemm_tuning(args.gemm_picks)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -18,7 +18,8 @@ import torch
 DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable", "gfx950.csv")
 
 
-def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tuning_ms: int = 200) -> bool:
+def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tuning_ms: int = 200,
+                       rotating_buffer_mb: Optional[int] = None) -> bool:
     """-> True when TunableOp is active with ``path`` (existing file, or tuning requested)."""
     path = path or DEFAULT_FILE
     if not tune and not os.path.exists(path):
@@ -29,6 +30,8 @@ def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tunin
     if tune:
         t.set_filename(path, insert_device_ordinal=False)
         t.set_max_tuning_duration(int(max_tuning_ms))              # the results file is written by TunableOp as shapes are tuned / at exit
+        if rotating_buffer_mb is not None:                          # operands rotate through a buffer larger than the caches: candidates are timed cold, as in a real step
+            t.set_rotating_buffer_size(int(rotating_buffer_mb))
     else:
         t.read_file(path)
         # look-up only: whatever TunableOp may still want to write goes to a scratch file of this process, never to the
