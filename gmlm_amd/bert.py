@@ -180,7 +180,10 @@ class _Linear(torch.autograd.Function):
                 if need[i]:
                     grads[i] = g if g.dtype == m.dtype else g.to(m.dtype)
         if ctx.has_bias and any(need[n_w:]):
-            db = dy2.sum(0, dtype=torch.float32)
+            # the consumer may already hold the column sums (ops.AttentionQKV's short-sequence backward forms them in-kernel)
+            db = getattr(dy, "_gmlm_colsum", None)
+            if db is None or db.shape != (dy2.shape[-1],):
+                db = dy2.sum(0, dtype=torch.float32)
             for i, (m, g) in enumerate(zip(masters[n_w:], db.split([m.shape[0] for m in masters[n_w:]], 0))):
                 if need[n_w + i]:
                     grads[n_w + i] = g if g.dtype == m.dtype else g.to(m.dtype)

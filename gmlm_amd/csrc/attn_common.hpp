@@ -16,6 +16,7 @@ struct AttnParams {
   const int32_t* kv_len;
   const int32_t* cu;      // varlen (packed) mode: sequence b owns rows [cu[b], cu[b+1]) of q AND k/v; lq = total rows
   float* delta;
+  float* dbias_part;          // short-sequence backward: [sequences, 3, h*d] column sums of this workgroup's dQ / dK / dV rows (NULL = off)
   void *o_w, *dq, *dk, *dv;
   float* lse_w;
   int64_t b, h, lq, lk;
@@ -98,6 +99,30 @@ __device__ __forceinline__ void mma_acc(const bf16_t* ts, int pitch, int row0, c
     bf16x8 b;
 #pragma unroll
     for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[8 * s + j];
+    const bf16_t* base = ts + (row0 + 16 * s + 4 * hh + qq) * pitch + 16 * (g & 1) + 4 * pp;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db) {
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, base + db * 32));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, base + db * 32 + 8 * pitch));
+      bf16x8 a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+      out[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out[db], 0, 0, 0);
+    }
+  }
+}
+// out[db] += A(tile^T) * B with B[k][every column] = coef[tile row k] (bf16, in LDS): the matrix-vector product
+// tile^T coef on the matrix pipe; all 32 result columns are identical.  Same row order as mma_acc.
+template <int D>
+__device__ __forceinline__ void mma_acc_coef(const bf16_t* ts, int pitch, int row0, const bf16_t* coef, f32x16 (&out)[D / 32], int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3, hh = g >> 1;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const bf16x4 c0 = *reinterpret_cast<const bf16x4*>(coef + row0 + 16 * s + 4 * hh);        // rows +0..3
+    const bf16x4 c1 = *reinterpret_cast<const bf16x4*>(coef + row0 + 16 * s + 4 * hh + 8);    // rows +8..11
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { b[j] = c0[j]; b[4 + j] = c1[j]; }
     const bf16_t* base = ts + (row0 + 16 * s + 4 * hh + qq) * pitch + 16 * (g & 1) + 4 * pp;
 #pragma unroll
     for (int db = 0; db < D / 32; ++db) {

@@ -18,6 +18,7 @@
 //  * padding: keys >= kv_len[b] get probability exactly 0 (the reference adds finfo.min and
 //    softmaxes: the same zeros in fp32); whole tiles past kv_len are skipped.
 #include "attn_common.hpp"
+#include "colreduce.hpp"
 
 #include <type_traits>
 
@@ -558,8 +559,13 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
   T* tdo = tq + R * PITCH;
   float* lse_s = reinterpret_cast<float*>(tdo + R * PITCH);
   float* dl_s = lse_s + R;
+  // bias-gradient coefficients (p.dbias_part): per key c_k = sum_q dS[q,k], per query pm_q = sum_k P'[q,k] (bf16): [2][R]
+  T* coef = reinterpret_cast<T*>(dl_s + R);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
   const int64_t b = blockIdx.x / p.h, hd = blockIdx.x % p.h;
+  const bool bgrad = p.dbias_part != nullptr;                // block-uniform
+  if (bgrad)
+    for (int i = tid; i < 2 * R; i += NT) coef[i] = f32_to_bf16(0.f);     // waves that skip a phase leave zeros
   int64_t lq_, lk_, qbase, kbase, lse_base;
   seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
   int64_t kvlen = lk_;
@@ -627,6 +633,7 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
       for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
     // scores of one 32-key block -> dS^T; MASKED only for the block that straddles kv_len (block-uniform choice:
     // full blocks carry no per-key compare / select at all)
+    float pm = 0.f;                                         // this half-wave's share of sum_k P'[q,k] (dropped probabilities)
     auto block_ds = [&](auto masked_c, int kb, f32x16& s, const f32x16& dp) {
       constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
@@ -642,6 +649,7 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
         if (DROP) drop_pair_q(dq_u + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
         s[i] = p0 * (dp[i] * m0 - dl);
         s[i + 1] = p1 * (dp[i + 1] * m1 - dl);
+        if (bgrad) pm = fmaf(p1, m1, fmaf(p0, m0, pm));
       }
     };
 #pragma unroll
@@ -661,6 +669,10 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
 #pragma unroll
       for (int d = 0; d < DB; ++d) store_t<T>(dqg + d * 32, dq[d], p.scale, h);
     }
+    if (bgrad) {
+      pm = xhalf_sum(pm);
+      if (h == 0) coef[R + q_row] = f32_to_bf16(pm);
+    }
   }
   // ---- phase 2: dK, dV (key on the lane; Q, dO as MFMA A operands) -------------------------------------
   if (w * 32 < lk) {
@@ -678,6 +690,7 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
       const uint32_t dk_u = d_base + (uint32_t)(key >> 1) * kDropC2 + (uint32_t)(2 * h) * kDropC1;
       const int k_odd = key & 1;
       const float kmask = key < kvl ? 0.f : INFINITY;       // subtracted from the exponent: a masked key's probabilities are exactly 0
+      float ck = 0.f;                                       // this half-wave's share of sum_q dS[q,key]
 #pragma unroll
       for (int qb = 0; qb < R / 32; ++qb) {
         if (qb * 32 >= lq) break;                           // block-uniform
@@ -703,10 +716,15 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
             s[i + 1] = p1 * m1;
             dp[i] = p0 * (dp[i] * m0 - dq4[j]);
             dp[i + 1] = p1 * (dp[i + 1] * m1 - dq4[j + 1]);
+            if (bgrad) ck += dp[i] + dp[i + 1];
           }
         }
         mma_acc<D>(tdo, PITCH, qb * 32, s, dv, lane);
         mma_acc<D>(tq, PITCH, qb * 32, dp, dk, lane);
+      }
+      if (bgrad) {
+        ck = xhalf_sum(ck);
+        if (h == 0) coef[key] = f32_to_bf16(ck);
       }
     }
     if (key < lk) {
@@ -718,6 +736,37 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
         store_t<T>(dvg + d * 32, dv[d], 1.f, h);
       }
     }
+  }
+  // ---- bias gradients: column sums of this workgroup's dQ, dK, dV rows, WITHOUT a cross-lane reduction ----------
+  //   sum_q dQ[q,:] = scale * sum_k c_k K[k,:],  c_k = sum_q dS[q,k]          sum_k dV[k,:] = sum_q pm_q dO[q,:],  pm_q = sum_k P'[q,k]
+  //   sum_k dK[k,:] = scale * sum_q (sum_k dS[q,k]) Q[q,:] = 0: the rows of dS sum to zero (a key bias shifts every score of
+  //   a query alike and the softmax does not see it; the reference's autograd returns rounding noise of order 1e-8 there).
+  // Two matrix-vector products with tiles that are already in LDS: tile^T on the MFMA A side (ds_read_b64_tr_b16), the
+  // coefficient vector broadcast on the B side; one (tensor, 32-column block) unit per wave.
+  if (bgrad) {
+    __syncthreads();                                       // coefficients of every wave are in LDS
+    float* outp = p.dbias_part + (b * 3 * p.h + hd) * D;
+    for (int u = w; u < 2 * DB; u += R / 32) {             // wave-uniform
+      const int t = u / DB, db = u % DB;                   // t = 0: dQ sums from (K tile, c), t = 1: dV sums from (dO tile, pm)
+      const T* tile = (t == 0 ? tk : tdo) + db * 32;
+      const T* cf = coef + t * R;
+      const int rows = t == 0 ? lk : lq;
+      f32x16 acc[1];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
+#pragma unroll
+      for (int rb = 0; rb < R / 32; ++rb) {
+        if (rb * 32 >= rows) break;
+        mma_acc_coef<32>(tile, PITCH, rb * 32, cf, acc, lane);
+      }
+      if (r == 0) {                                        // every column holds the same vector: column 0 of each half writes its rows
+        const float mul = t == 0 ? p.scale : 1.f;
+        float* o2 = outp + (t == 0 ? 0 : 2) * p.h * D + db * 32;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o2[acc_row(i, h)] = acc[0][i] * mul;
+      }
+    }
+    if (tid < D) outp[p.h * D + tid] = 0.f;               // dK column sums
   }
 }
 
@@ -957,8 +1006,10 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
                                   int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
                                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                                   int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
-                                  void* workspace, size_t workspace_bytes, gmlm_stream_t stream) {
+                                  void* workspace, size_t workspace_bytes, float* dbias_partial, float* dbias,
+                                  gmlm_stream_t stream) {
   int rc = attn_check("attention_bwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE((dbias_partial == nullptr) == (dbias == nullptr), "attention_bwd: dbias_partial and dbias come together");
   GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_bwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
   if (rc != GMLM_OK) return rc;
   if (b == 0 || (lq == 0 && lk == 0)) return GMLM_OK;
@@ -979,14 +1030,14 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   const int64_t rows_q = cu_seqlens ? max_len : lq, rows_k = cu_seqlens ? max_len : lk;
   const int64_t nb = cu_seqlens ? 1 : b;        // delta kernel: packed tensors are one [total_rows, h, d] block
   p.delta = static_cast<float*>(workspace);
-  p.dq = dq; p.dk = dk; p.dv = dv;
+  p.dq = dq; p.dk = dk; p.dv = dv; p.dbias_part = dbias_partial;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
   p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed; p.seed_dev = seed_dev;
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && rows_k <= 128 && b * h >= 512) {
     // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace
     static bool attr_set = false;
-    auto lds_of = [](int r) { return (size_t)4 * r * (64 + 8) * sizeof(bf16_t) + 2 * r * sizeof(float); };   // K, V, Q, dO images + lse, delta
+    auto lds_of = [](int r) { return (size_t)4 * r * (64 + 8) * sizeof(bf16_t) + 2 * r * sizeof(float) + 2 * r * sizeof(bf16_t); };   // K, V, Q, dO images + lse, delta + bias-gradient coefficients
     if (!attr_set) {
 #define GMLM_SHORT_ATTR(RR)                                                                                                        \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
@@ -1005,8 +1056,14 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     GMLM_SHORT_LAUNCH(128) GMLM_SHORT_LAUNCH(96) GMLM_SHORT_LAUNCH(64) GMLM_SHORT_LAUNCH(32)
 #undef GMLM_SHORT_LAUNCH
     GMLM_LAUNCH_CHECK();
+    if (dbias) {                                           // [sequences, 3 h d] partial column sums -> [3 h d], fixed order
+      const int64_t width = 3 * h * d;
+      rows_sum_kernel<<<(unsigned)cdiv(width, 32), 256, 0, st>>>(dbias_partial, (int)b, width, dbias, 1.f);
+      GMLM_LAUNCH_CHECK();
+    }
     return GMLM_OK;
   }
+  GMLM_REQUIRE(!dbias, "attention_bwd: the fused bias-gradient sums exist only on the short-sequence path (bf16, d = 64, <= 128 rows, b*h >= 512)");
   const int64_t rows = nb * lq * h;
   {
     const int cpr = (int)d / (dtype == GMLM_BF16 ? 8 : 4);

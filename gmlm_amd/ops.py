@@ -395,7 +395,7 @@ class Attention(torch.autograd.Function):
             sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, sd, _ptr(dq),
-                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), _stream()),
+                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), None, None, _stream()),
                   "gmlm_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
 
@@ -448,12 +448,23 @@ class AttentionQKV(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         dq, dk, dv = dqkv[..., :hd], dqkv[..., hd:2 * hd], dqkv[..., 2 * hd:]
         ws = _ws(lib().gmlm_attention_bwd_workspace_bytes(1 if cu_seqlens is not None else b, h, l, l, d), qkv.device)
+        # short-sequence path (one launch per (sequence, head): same condition as the C entry): the column sums of dqkv --
+        # the bias gradient of the fused QKV projection that produced qkv -- come out of the kernel as well
+        rows = max_len if cu_seqlens is not None else l
+        fused_db = qkv.dtype == torch.bfloat16 and d == 64 and rows <= 128 and b * h >= 512
+        part = db = None
+        if fused_db:
+            part = _ws(4 * b * hd3, qkv.device).view(torch.float32)
+            db = torch.empty(hd3, dtype=torch.float32, device=qkv.device)
         with _span("attn_bwd_d%d" % d, flops=2.5 * flops):
             sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            l, l, d, hd3, hd3, hd3, scale, p, seed, sd, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
-                                           hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _stream()),
+                                           hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _ptr(part), _ptr(db),
+                                           _stream()),
                   "gmlm_attention_bwd")
+        if db is not None:
+            dqkv._gmlm_colsum = db            # picked up by the producer's backward (bert._Linear) instead of a pass over dqkv
         return dqkv, None, None, None, None, None, None, None, None
 
 
@@ -493,7 +504,7 @@ class AttentionBlock:
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(kv_len), b, self.h,
                                            lq, lk, d, _rows_view(q, self.h, d), _rows_view(k, self.h, d), _rows_view(v, self.h, d),
                                            self.scale, self.p, int(seed), sd, _ptr(dq), _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0,
-                                           _ptr(ws), ws.numel(), _stream()), "gmlm_attention_bwd")
+                                           _ptr(ws), ws.numel(), None, None, _stream()), "gmlm_attention_bwd")
         return dq, dk, dv
 
 

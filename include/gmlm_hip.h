@@ -205,7 +205,12 @@ int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* 
                        int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride, float scale,
                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                        int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
-                       void* workspace, size_t workspace_bytes, gmlm_stream_t stream);
+                       void* workspace, size_t workspace_bytes,
+                       float* dbias_partial /* [b, 3*h*d] scratch */, float* dbias /* [3*h*d]: column sums of dq | dk | dv over all rows */,
+                       gmlm_stream_t stream);
+/* dbias (optional, both pointers or neither; short-sequence path only, EINVAL otherwise): the bias gradient of a fused
+ * QKV projection, sum over rows of [dq | dk | dv], formed inside the backward kernel from tiles it already holds
+ * (three matrix-vector products on the MFMA pipe) instead of a separate pass over dqkv. */
 
 /* ---------------------------------------------------------------------------------------------
  * K8  attention-mask-weighted mean pooling + row scatter          (main.py:351-358)

@@ -531,13 +531,32 @@ def test_attention_fused_short_sequence_backward(dev):
     tot = int(cu[-1])
     qkv = (torch.randn(tot, 3 * h * d, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
     go = torch.randn(tot, h * d, generator=g).to(dev, torch.bfloat16)
-    y = attention_qkv(qkv, None, h, d ** -0.5, 0.0, False, cu.to(dev), 128)
+    seen = {}
+
+    class Producer(torch.autograd.Function):                 # stands where bert._Linear stands: receives dqkv as its grad_output
+        @staticmethod
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, dy):
+            seen["colsum"] = getattr(dy, "_gmlm_colsum", None)
+            return dy
+
+    y = attention_qkv(Producer.apply(qkv), None, h, d ** -0.5, 0.0, False, cu.to(dev), 128)
     y.backward(go)
     yr, gr = _packed_ref_grads(qkv.detach(), go, lens, h, d, d ** -0.5)
     assert float((y.detach().float() - yr).abs().max()) <= 2e-2 * float(yr.abs().max())
     for j, name in enumerate("qkv"):
         a, r = qkv.grad[:, j * h * d:(j + 1) * h * d].float(), gr[:, j * h * d:(j + 1) * h * d]
         assert float((a - r).abs().max()) <= 2e-2 * float(r.abs().max()), name
+    # the same launch also returns the column sums of dqkv (the fused QKV projection's bias gradient), formed from the
+    # LDS tiles by three matrix-vector MFMAs per (sequence, head): against the fp32 reference's column sums
+    db = seen.get("colsum")
+    assert db is not None and db.shape == (3 * h * d,) and db.dtype == torch.float32
+    db_ref = gr.sum(0)
+    assert float((db.cpu() - db_ref.cpu()).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
+    assert float((db - qkv.grad.float().sum(0)).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
     # dropout: sequences of <= 64 tokens so that V = I (L x 64) exposes the dropped probabilities
     lens2 = torch.cat([torch.tensor([1, 2, 33, 64]), torch.randint(1, 65, (44,), generator=g)])
     cu2 = torch.zeros(lens2.numel() + 1, dtype=torch.int32)

@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     const uint64_t seed = 0x1234567ull;
     // exact-f32 reference (same dropout hash -> same mask)
     GK(gmlm_attention_fwd(qf, kf, vf, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, of, lsef, GMLM_F32, nullptr, 0, nullptr));
-    if (do_bwd) GK(gmlm_attention_bwd(qf, kf, vf, of, gof, lsef, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dqf, dkf, dvf, st, st, st, GMLM_F32, nullptr, 0, ws, wsb, nullptr));
+    if (do_bwd) GK(gmlm_attention_bwd(qf, kf, vf, of, gof, lsef, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dqf, dkf, dvf, st, st, st, GMLM_F32, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> ro(n), rl(rows * c.h), rdq(n), rdk(n), rdv(n);
     CK(hipMemcpy(ro.data(), of, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rl.data(), lsef, rows * c.h * 4, hipMemcpyDeviceToHost));
@@ -164,7 +164,7 @@ int main(int argc, char** argv) {
       printf("%-14s var=%d fwd %8.1f us  %7.1f TF/s padded (%.3f of 2.5 PF)  %7.1f TF/s executed   max|o-f32|=%.4f max|lse-f32|=%.5f nan=%ld\n",
              c.tag, var, ms * 1e3, padded / ms / 1e9, padded / ms / 1e9 / 2500.0, useful / ms / 1e9, eo, el, (long)bad);
       if (do_bwd) {
-        GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr));
+        GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
         CK(hipDeviceSynchronize());
         std::vector<uint16_t> g(n);
         double e3[3] = {0, 0, 0}, m3[3] = {0, 0, 0};
@@ -173,9 +173,9 @@ int main(int argc, char** argv) {
           CK(hipMemcpy(g.data(), dptr[t], n * 2, hipMemcpyDeviceToHost));
           for (int64_t i = 0; i < n; ++i) { const double x = bf2f(g[i]), e = fabs(x - (*rp[t])[i]); if (!(x == x)) ++bad; if (e > e3[t]) e3[t] = e; if (fabs((*rp[t])[i]) > m3[t]) m3[t] = fabs((*rp[t])[i]); }
         }
-        for (int i = 0; i < 3; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr));
+        for (int i = 0; i < 3; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
         CK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr));
+        for (int i = 0; i < iters; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
         CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         printf("%-14s var=%d bwd %8.1f us  %7.1f TF/s padded(10/4 x fwd flops) (%.3f)  err dq %.4f/%.2f dk %.4f/%.2f dv %.4f/%.2f nan=%ld\n", c.tag, var, ms * 1e3,
@@ -219,10 +219,10 @@ int main(int argc, char** argv) {
     };
     auto bwd = [&]() {
       if (!by_class) { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
-                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr)); return; }
+                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr, nullptr, nullptr)); return; }
       for (auto& c : cls)      // one call per capacity class: same tensors, cu_seqlens sub-range, the class's own max_len
         GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
-                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr));
+                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr, nullptr, nullptr));
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms;
