@@ -234,16 +234,27 @@ class GraphTextLM(nn.Module):
                     # variable-length packing: only real tokens exist; index arithmetic from the HOST copy of the
                     # lengths (sizes known without a device sync), token gather on the device
                     total = int(lh.sum())
-                    cu_h = torch.zeros(bi.numel() + 1, dtype=torch.int32)
-                    cu_h[1:] = torch.cumsum(lh, 0)
-                    cu = to_dev(cu_h)
+                    # large batches: pad the token count to a multiple of 16 with ONE dummy sequence of [PAD] tokens behind the
+                    # real ones (never pooled, zero gradient): the split-K weight-gradient GEMMs then cut T into 16 equal slices
+                    # with no tail rows (a tail is one more tiny GEMM and a full pass over dW per weight: 2 x 48 launches per
+                    # BERT-base step), and every GEMM sees an aligned row count
+                    pad = (-total) % 16 if (total >= 4096 and lmax >= 16) else 0
+                    cu_h = torch.zeros(bi.numel() + 1 + (1 if pad else 0), dtype=torch.int32)
+                    cu_h[1:bi.numel() + 1] = torch.cumsum(lh, 0)
+                    if pad:
+                        cu_h[-1] = total + pad
+                    cu_all = to_dev(cu_h)
+                    cu = cu_all[:bi.numel() + 1]
                     seq = torch.repeat_interleave(torch.arange(bi.numel(), device=dev), lens.long(), output_size=total)
                     pos = torch.arange(total, device=dev) - cu[seq].long()
                     tok = tokens.input_ids[bi[seq], pos]
-                    hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu, lmax, cd, self.plm_encoder.training,
+                    if pad:
+                        tok = torch.cat([tok, tok.new_zeros(pad)])
+                        pos = torch.cat([pos, torch.arange(pad, device=dev)])
+                    hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu_all, lmax, cd, self.plm_encoder.training,
                                                  self.plm_gradient_checkpointing, weights,
-                                                 pair_count=float((lh.double() ** 2).sum()))
-                    plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, None, bi, cu)
+                                                 pair_count=float((lh.double() ** 2).sum()) + float(pad * pad))
+                    plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, None, bi, cu, total)
                 else:
                     ids = tokens.input_ids[bi, :lmax]
                     hs = bert.bert_encode(self.plm_encoder, ids, lens, cd, self.plm_encoder.training,

@@ -526,7 +526,9 @@ class MeanPoolScatter(torch.autograd.Function):
     hs is [b, l, p] (padded, ``lens``) or [total_rows, p] (packed, ``cu_seqlens``)."""
 
     @staticmethod
-    def forward(ctx, plm_embeds, hs, lens, node_idx, cu_seqlens=None):
+    def forward(ctx, plm_embeds, hs, lens, node_idx, cu_seqlens=None, valid_rows=None):
+        """``valid_rows`` (packed): rows of ``hs`` covered by ``cu_seqlens``; rows behind them (padding the token count to a
+        friendlier multiple) get a zero gradient."""
         _cuda(hs, plm_embeds)
         hs = hs.contiguous()
         if cu_seqlens is not None:
@@ -537,20 +539,22 @@ class MeanPoolScatter(torch.autograd.Function):
                                               _ptr(cu_seqlens), _stream()), "gmlm_meanpool_scatter_fwd")
         ctx.mark_dirty(plm_embeds)
         ctx.save_for_backward(lens, node_idx, cu_seqlens)
-        ctx.cfg = (b, l, p, hs.dtype, tuple(hs.shape))
+        ctx.cfg = (b, l, p, hs.dtype, tuple(hs.shape), valid_rows)
         return plm_embeds
 
     @staticmethod
     def backward(ctx, g):
         lens, node_idx, cu_seqlens = ctx.saved_tensors
-        b, l, p, dtype, shape = ctx.cfg
+        b, l, p, dtype, shape, valid_rows = ctx.cfg
         g = g.contiguous().float()
         dhs = torch.empty(shape, dtype=dtype, device=g.device)
+        if valid_rows is not None and valid_rows < shape[0]:
+            dhs[valid_rows:].zero_()
         check(lib().gmlm_meanpool_scatter_bwd(_ptr(g), _ptr(lens), _ptr(node_idx), b, l, p, _ptr(dhs), _dt(dhs),
                                               _ptr(cu_seqlens), _stream()), "gmlm_meanpool_scatter_bwd")
         # rows written by this micro-batch were overwritten: no gradient flows to their previous value;
         # the previous value is the zero-initialised buffer (a constant), so passing g through is harmless.
-        return g, dhs, None, None, None
+        return g, dhs, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------
