@@ -3,8 +3,8 @@ fp32-output batched GEMM (what bert._splitk_wgrad issues; not covered by Tunable
 that TunableOp can tune.  usage: [PYTORCH_TUNABLEOP_ENABLED=1] python tools/ubench/wgrad_shapes.py"""
 import torch
 dev = torch.device("cuda")
-T, S = 91698, 16
-q = T // S
+import sys
+T = 91712
 
 def timeit(f, n=20):
     for _ in range(3): f()
@@ -16,8 +16,10 @@ def timeit(f, n=20):
     return e0.elapsed_time(e1) / n * 1e3
 
 for name, n, k in (("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)):
-    dy = torch.randn(T, n, device=dev, dtype=torch.bfloat16)
-    x = torch.randn(T, k, device=dev, dtype=torch.bfloat16)
+  dy = torch.randn(T, n, device=dev, dtype=torch.bfloat16)
+  x = torch.randn(T, k, device=dev, dtype=torch.bfloat16)
+  for S in (8, 16, 32):
+    q = T // S
     a = dy[:S * q].view(S, q, n).transpose(1, 2)
     b = x[:S * q].view(S, q, k)
     fl = 2.0 * S * q * n * k
@@ -25,4 +27,4 @@ for name, n, k in (("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("f
     t16 = timeit(lambda: torch.bmm(a, b).float().sum(0))
     t32g = timeit(lambda: torch.bmm(a, b, out_dtype=torch.float32))
     t16g = timeit(lambda: torch.bmm(a, b))
-    print(f"{name:5s} f32-out {t32:7.1f} us ({fl / t32 / 1e6:6.1f} TF/s; GEMM alone {t32g:7.1f})   bf16-out {t16:7.1f} us ({fl / t16 / 1e6:6.1f} TF/s; GEMM alone {t16g:7.1f})")
+    print(f"{name:5s} S={S:2d} f32-out {t32:7.1f} us ({fl / t32 / 1e6:6.1f} TF/s; GEMM alone {t32g:7.1f})   bf16-out {t16:7.1f} us ({fl / t16 / 1e6:6.1f} TF/s; GEMM alone {t16g:7.1f})")
