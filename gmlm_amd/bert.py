@@ -248,10 +248,11 @@ def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_s
     (same result per token as the padded form: padded keys have probability exactly 0 there)."""
     cfg = plm.config
     emb = plm.embeddings
-    x = torch.nn.functional.embedding(token_ids.long(), emb.word_embeddings.weight)
-    x = x + emb.token_type_embeddings.weight[0] + torch.nn.functional.embedding(pos_ids.long(), emb.position_embeddings.weight)
+    # word + type-0 + position rows in one pass (fp32 sums in torch's order, stored as cd); backward = segment sums by id
+    x = ops.embed_sum(token_ids, pos_ids, emb.word_embeddings.weight, emb.position_embeddings.weight,
+                      emb.token_type_embeddings.weight, cd)
     eps, p_hidden, p_attn = cfg.layer_norm_eps, cfg.hidden_dropout_prob, cfg.attention_probs_dropout_prob
-    h = ops.bias_res_layernorm(x.to(cd), None, None, emb.LayerNorm.weight, emb.LayerNorm.bias, eps, False, p_hidden, training)
+    h = ops.bias_res_layernorm(x, None, None, emb.LayerNorm.weight, emb.LayerNorm.bias, eps, False, p_hidden, training)
     heads = cfg.num_attention_heads
     d = cfg.hidden_size // heads
     if d not in (64, 96):

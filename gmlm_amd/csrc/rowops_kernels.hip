@@ -297,3 +297,57 @@ extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bi
   }
   return GMLM_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// BERT embedding sum: out[t, :] = word[tok[t], :] + type0[:] + pos[pos_ids[t], :]   (hf:modeling_bert.py:53-108 before the
+// LayerNorm; one pass instead of two gathers, two adds and a cast).  fp32 tables, fp32 adds in that order (the same
+// values the three torch ops produce), stored as `dtype`.  One wave handles a row: 64 lanes x float4 = 256 columns per step.
+// ------------------------------------------------------------------------------------------------
+namespace gmlm {
+template <typename T>
+__global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const float* __restrict__ word, const float* __restrict__ pos,
+                                                             const float* __restrict__ type0, const int64_t* __restrict__ tok,
+                                                             const int64_t* __restrict__ pos_ids, int64_t rows, int p, int64_t vocab,
+                                                             int64_t npos, T* __restrict__ out) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < rows; r += (int64_t)gridDim.x * 4) {
+    int64_t tv = tok[r], pv = pos_ids[r];
+    tv = tv < 0 ? 0 : (tv >= vocab ? vocab - 1 : tv);          // ids are validated by the caller; never read out of bounds
+    pv = pv < 0 ? 0 : (pv >= npos ? npos - 1 : pv);
+    const float* wr = word + tv * p;
+    const float* pr = pos + pv * p;
+    for (int c = lane * 4; c < p; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(wr + c);
+      const float4 t4 = *reinterpret_cast<const float4*>(type0 + c);
+      const float4 b = *reinterpret_cast<const float4*>(pr + c);
+      const float o[4] = {(a.x + t4.x) + b.x, (a.y + t4.y) + b.y, (a.z + t4.z) + b.z, (a.w + t4.w) + b.w};
+      if constexpr (sizeof(T) == 4) {
+        *reinterpret_cast<float4*>(out + r * p + c) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+        uint2 v;
+        v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        v.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        *reinterpret_cast<uint2*>(out + r * p + c) = v;
+      }
+    }
+  }
+}
+}  // namespace gmlm
+
+extern "C" int gmlm_embed_sum_fwd(const float* word, const float* pos, const float* type0, const int64_t* tok,
+                                  const int64_t* pos_ids, int64_t rows, int64_t p, int64_t vocab, int64_t npos, void* out,
+                                  int dtype, gmlm_stream_t stream) {
+  using namespace gmlm;
+  GMLM_REQUIRE(rows >= 0 && p > 0 && p % 4 == 0 && vocab > 0 && npos > 0, "embed_sum_fwd: bad sizes (p must be a multiple of 4)");
+  GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "embed_sum_fwd: dtype must be GMLM_F32 or GMLM_BF16");
+  if (rows == 0) return GMLM_OK;
+  GMLM_REQUIRE(word && pos && type0 && tok && pos_ids && out, "embed_sum_fwd: null pointer");
+  GMLM_REQUIRE(aligned16(word) && aligned16(pos) && aligned16(type0) && aligned16(out), "embed_sum_fwd: tables / output must be 16-byte aligned");
+  const unsigned grid = (unsigned)(cdiv(rows, 4) < 65536 ? cdiv(rows, 4) : 65536);
+  if (dtype == GMLM_F32)
+    embed_sum_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (float*)out);
+  else
+    embed_sum_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (bf16_t*)out);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}

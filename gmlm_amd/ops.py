@@ -558,6 +558,49 @@ class MeanPoolScatter(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------
+# BERT embedding sum (word + token type 0 + position) and its segment-sum backward
+# ---------------------------------------------------------------------------------------------
+class EmbedSum(torch.autograd.Function):
+    """out[t] = word[tok[t]] + type[0] + pos[pos_ids[t]]  (hf:modeling_bert.py:53-108 ahead of the LayerNorm) stored as
+    ``out_dtype``: one pass instead of two gathers, two adds and a cast.  Backward: the output gradient is summed per token id
+    and per position id with the aggregation kernel over a stable segment sort of the ids (K1 + K2: deterministic, no atomics);
+    the type-0 row's gradient is the sum of the position rows' gradients (every token has exactly one position)."""
+
+    @staticmethod
+    def forward(ctx, tok, pos_ids, word_w, pos_w, type_w, out_dtype):
+        _cuda(word_w, pos_w, type_w)
+        tok, pos_ids = tok.long().contiguous(), pos_ids.long().contiguous()
+        word, pos, typ = _f32c(word_w), _f32c(pos_w), _f32c(type_w)
+        rows, p = tok.numel(), word.shape[1]
+        out = torch.empty(rows, p, dtype=out_dtype, device=word.device)
+        check(lib().gmlm_embed_sum_fwd(_ptr(word), _ptr(pos), _ptr(typ), _ptr(tok), _ptr(pos_ids), rows, p, word.shape[0],
+                                       pos.shape[0], _ptr(out), _dt(out), _stream()), "gmlm_embed_sum_fwd")
+        ctx.save_for_backward(tok, pos_ids)
+        ctx.cfg = (word.shape[0], pos.shape[0], type_w.shape[0], p)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .graph import _segment_sort
+        tok, pos_ids = ctx.saved_tensors
+        vocab, npos, ntype, p = ctx.cfg
+        g = g.contiguous()
+        grads = []
+        for ids, nseg in ((tok, vocab), (pos_ids, npos)):
+            _, perm, rowptr, _ = _segment_sort(ids, None, None, 1, nseg)
+            acc = torch.empty(nseg, p, dtype=g.dtype, device=g.device)
+            _spmm(g, rowptr, perm, None, False, nseg, p, acc)
+            grads.append(acc.float())
+        d_type = torch.zeros(ntype, p, dtype=torch.float32, device=g.device)
+        d_type[0] = grads[1].sum(0)
+        return None, None, grads[0], grads[1], d_type, None
+
+
+def embed_sum(tok, pos_ids, word_w, pos_w, type_w, out_dtype):
+    return EmbedSum.apply(tok, pos_ids, word_w, pos_w, type_w, out_dtype)
+
+
+# ---------------------------------------------------------------------------------------------
 # K9: soft-mask blend
 # ---------------------------------------------------------------------------------------------
 class SoftMask(torch.autograd.Function):

@@ -212,6 +212,12 @@ int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* 
  * QKV projection, sum over rows of [dq | dk | dv], formed inside the backward kernel from tiles it already holds
  * (three matrix-vector products on the MFMA pipe) instead of a separate pass over dqkv. */
 
+/* BERT embedding sum (hf:modeling_bert.py:53-108 ahead of the LayerNorm): out[t] = word[tok[t]] + type0 + pos[pos_ids[t]],
+ * fp32 tables, stored as `dtype` [rows, p]; replaces two gathers, two adds and a cast.  Its backward is a segment sum of the
+ * output gradient by token id / position id (gmlm_segment_sort + gmlm_rgcn_mean_spmm with mean = 0). */
+int gmlm_embed_sum_fwd(const float* word, const float* pos, const float* type0, const int64_t* tok, const int64_t* pos_ids,
+                       int64_t rows, int64_t p, int64_t vocab, int64_t npos, void* out, int dtype, gmlm_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K8  attention-mask-weighted mean pooling + row scatter          (main.py:351-358)
  * out[node_idx[b], :] = sum_t hs[b,t,:] * [t < len[b]] / max(len[b], 1e-9)     (out fp32 [n, p])

@@ -621,3 +621,32 @@ def test_csr_and_spmm_random_shapes_property(dev):
         xr = x.clone().requires_grad_(True)
         (O.rgcn_mean_aggregate(xr, ei, et_slot, len(act)).permute(1, 0, 2).reshape(n, -1) * gout).sum().backward()
         np.testing.assert_allclose(xd.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-5, err_msg=str(case))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_sum_matches_torch_gathers(dev, dtype):
+    """BERT embedding sum (hf:modeling_bert.py:53-108): one pass = F.embedding(tok, word) + type[0] + F.embedding(pos, position),
+    bit-exact in the forward (fp32 sums in the same order, one rounding to the storage dtype); the backward's segment sums by token /
+    position id against torch's embedding backward."""
+    from gmlm_amd import ops
+    g = torch.Generator().manual_seed(31)
+    vocab, npos, p, rows = 997, 128, 768, 20011
+    word = torch.randn(vocab, p, generator=g).to(dev).requires_grad_(True)
+    pos = torch.randn(npos, p, generator=g).to(dev).requires_grad_(True)
+    typ = torch.randn(2, p, generator=g).to(dev).requires_grad_(True)
+    tok = torch.randint(0, vocab, (rows,), generator=g)
+    tok[:3000] = 7                                              # a hot token: one long segment
+    pid = torch.randint(0, npos, (rows,), generator=g)
+    tok, pid = tok.to(dev), pid.to(dev)
+    go = torch.randn(rows, p, generator=g).to(dev, dtype)
+    out = ops.embed_sum(tok, pid, word, pos, typ, dtype)
+    ref = (F.embedding(tok, word) + typ[0] + F.embedding(pid, pos))
+    assert torch.equal(out, ref.to(dtype))
+    out.backward(go)
+    gw, gp, gt = word.grad.clone(), pos.grad.clone(), typ.grad.clone()
+    word.grad = pos.grad = typ.grad = None
+    ref.backward(go.float())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2                  # bf16: the segment sums are stored as bf16 once
+    for a, r in ((gw, word.grad), (gp, pos.grad), (gt, typ.grad)):
+        assert float((a - r).abs().max()) <= tol * float(r.abs().max()) + 1e-6
+    assert float(gt[1].abs().max()) == 0.0
