@@ -193,7 +193,9 @@ int main(int argc, char** argv) {
     std::vector<int32_t> cu(nseq + 1, 0);
     double pairs = 0;
     std::vector<int> lens(nseq);
-    for (auto& x : lens) x = 16 + (int)(rng() % 113);
+    const int lmax_ = getenv("GMLM_BENCH_MAXLEN") ? atoi(getenv("GMLM_BENCH_MAXLEN")) : 128;      // longest sequence of the mix
+    const int cls_ = getenv("GMLM_BENCH_CLASSLEN") ? atoi(getenv("GMLM_BENCH_CLASSLEN")) : lmax_;      // max_len handed to the library (capacity class)
+    for (auto& x : lens) x = 16 + (int)(rng() % (lmax_ - 15));
     std::sort(lens.begin(), lens.end(), [](int a, int b) { return a > b; });      // the encoder batches by length (descending)
     for (int64_t i = 0; i < nseq; ++i) { cu[i + 1] = cu[i] + lens[i]; pairs += (double)lens[i] * lens[i]; }
     // capacity classes (rows rounded up to 32): contiguous ranges of the sorted batch
@@ -213,13 +215,13 @@ int main(int argc, char** argv) {
     const float scale = 0.125f;
     const bool by_class = getenv("GMLM_BENCH_CLASSES") != nullptr;
     auto fwd = [&]() {
-      if (!by_class) { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr, o, lse, GMLM_BF16, dcu, 128, nullptr)); return; }
+      if (!by_class) { GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr, o, lse, GMLM_BF16, dcu, cls_, nullptr)); return; }
       for (auto& c : cls)
         GK(gmlm_attention_fwd(qkv, qkv + hd, qkv + 2 * hd, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr, o, lse, GMLM_BF16, dcu + c.first, lens[c.first], nullptr));
     };
     auto bwd = [&]() {
       if (!by_class) { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
-                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, 128, ws, wsb, nullptr, nullptr, nullptr)); return; }
+                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, cls_, ws, wsb, nullptr, nullptr, nullptr)); return; }
       for (auto& c : cls)      // one call per capacity class: same tensors, cu_seqlens sub-range, the class's own max_len
         GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
                               dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr, nullptr, nullptr));
