@@ -111,6 +111,45 @@ __device__ __forceinline__ void mma_acc(const bf16_t* ts, int pitch, int row0, c
     }
   }
 }
+// ---- dense (unpadded) d = 64 tile images with an XOR swizzle of the 16-byte slot index: 128-byte rows, no padding bytes.
+// Row-operand image (mma_rows_sw): slot = chunk ^ ((row >> 1) & 7): the 16 rows of a ds_read_b128 phase hit 16 distinct
+// (row parity, slot) positions = all 64 banks once.  Transposed-read image (mma_acc_sw): slot = chunk ^ (4 * ((row >> 1) & 1)):
+// the four rows of a ds_read_b64_tr_b16 quarter land in four different bank quarters.  (Same functions as the pipelined
+// forward's K / V images, attn_fwd_pipe.hip.)
+__device__ __forceinline__ int sw_row(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int sw_tr(int row) { return 4 * ((row >> 1) & 1); }
+__device__ __forceinline__ void mma_rows_sw(const bf16_t* ts, int row0, const RowFrag<bf16_t, 64>& f, f32x16& acc, int r, int h) {
+  const bf16_t* rowp = ts + (row0 + r) * 64;
+  const int x = sw_row(row0 + r);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(rowp + (((2 * s + h) ^ x) << 3));
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, f.v[s], acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ void mma_acc_sw(const bf16_t* ts, int row0, const f32x16& x, f32x16 (&out)[2], int lane) {
+  const int g = lane >> 4, i = lane & 15, qq = i >> 2, pp = i & 3, hh = g >> 1;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    bf16x8 b;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (__bf16)x[8 * s + j];
+    const int row = row0 + 16 * s + 4 * hh + qq;                       // the +8 row of the hi half has the same swizzle phase
+    const bf16_t* rowp = ts + row * 64 + 4 * (pp & 1);
+    const int xs = sw_tr(row);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+      const int slot = (4 * db + 2 * (g & 1) + (pp >> 1)) ^ xs;
+      const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, rowp + (slot << 3)));
+      const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(GMLM_LDS3(bf16x4, rowp + (slot << 3) + 8 * 64));
+      bf16x8 a;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+      out[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, out[db], 0, 0, 0);
+    }
+  }
+}
+
 // out[db] += A(tile^T) * B with B[k][every column] = coef[tile row k] (bf16, in LDS): the matrix-vector product
 // tile^T coef on the matrix pipe; all 32 result columns are identical.  Same row order as mma_acc.
 template <int D>

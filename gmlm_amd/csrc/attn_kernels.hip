@@ -779,7 +779,8 @@ __global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
 template <int D, bool DROP, int R>
 __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
   using T = bf16_t;
-  constexpr int NT = 2 * R, PITCH = D + Pad<T>::v, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;
+  static_assert(D == 64, "dense swizzled images are laid out for d = 64");
+  constexpr int NT = 2 * R, PITCH = D, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;   // dense rows: 48 KB at R = 128 = three workgroups per CU
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tk = reinterpret_cast<T*>(smem_raw);
   T* tv = tk + R * PITCH;
@@ -807,17 +808,18 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
-    *reinterpret_cast<uint4*>(tk + row * PITCH + col) = rk[k];
-    *reinterpret_cast<uint4*>(tv + row * PITCH + col) = rv[k];
-    *reinterpret_cast<uint4*>(tq + row * PITCH + col) = rq[k];
+    const int i = tid + k * NT, row = i / CPR;
+    const int c = i % CPR;                                      // 16-byte chunk of the row -> swizzled slot (attn_common.hpp)
+    *reinterpret_cast<uint4*>(tk + row * PITCH + ((c ^ sw_row(row)) << 3)) = rk[k];
+    *reinterpret_cast<uint4*>(tv + row * PITCH + ((c ^ sw_tr(row)) << 3)) = rv[k];
+    *reinterpret_cast<uint4*>(tq + row * PITCH + ((c ^ sw_row(row)) << 3)) = rq[k];
   }
   __syncthreads();
   if (w * 32 >= lq) return;                                   // (no barrier below)
   const int q_row = w * 32 + r;
   RowFrag<T, D> qf;
 #pragma unroll
-  for (int s = 0; s < D / 16; ++s) qf.v[s] = *reinterpret_cast<const bf16x8*>(tq + q_row * PITCH + 16 * s + 8 * h);
+  for (int s = 0; s < D / 16; ++s) qf.v[s] = *reinterpret_cast<const bf16x8*>(tq + q_row * PITCH + (((2 * s + h) ^ sw_row(q_row)) << 3));
   const float sl2 = p.scale * kLog2e;
   const int nblk = (kvl + 31) / 32;                           // block-uniform
   f32x16 s[NB];
@@ -827,7 +829,7 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
     if (kb >= nblk) break;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-    mma_rows<D>(tk, PITCH, kb * 32, qf, s[kb], r, h);
+    mma_rows_sw(tk, kb * 32, qf, s[kb], r, h);
     if ((kb + 1) * 32 > kvl) {                                // the block that straddles kv_len
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = kb * 32 + acc_row(i, h) < kvl ? s[kb][i] : -INFINITY;
@@ -855,7 +857,7 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
       s[kb][i] = e0 * m0;
       s[kb][i + 1] = e1 * m1;
     }
-    mma_acc<D>(tv, PITCH, kb * 32, s[kb], o, lane);
+    mma_acc_sw(tv, kb * 32, s[kb], o, lane);
   }
   l = xhalf_sum(l);
   if (q_row < lq) {
@@ -950,7 +952,7 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && (cu_seqlens ? max_len : lk) <= 128 && b * h >= 512) {
     // short sequences, enough of them to fill the chip: Q / K / V resident in LDS, one barrier (attn_fwd_short_kernel)
     static bool attr_set = false;
-    auto lds_of = [](int r) { return (size_t)3 * r * (64 + 8) * sizeof(bf16_t); };
+    auto lds_of = [](int r) { return (size_t)3 * r * 64 * sizeof(bf16_t); };        // dense swizzled Q / K / V images
     if (!attr_set) {
 #define GMLM_SHORT_ATTR(RR)                                                                                                        \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
