@@ -482,7 +482,11 @@ def main():
     if args.gemm_tune:
         gemm_tuning = tuning.enable_gemm_tuning(args.gemm_tune, tune=True, rotating_buffer_mb=args.gemm_tune_rotate)
     elif not args.no_gemm_tuning:
-        gemm_tuning = tuning.enable_gemm_tuning(args.gemm_picks)
+        try:
+            gemm_tuning = tuning.enable_gemm_tuning(args.gemm_picks)
+        except Exception as exc:        # the look-up is an optimisation: never a reason to lose the bench line
+            print(f"[bench] GEMM pick look-up unavailable ({exc!r}): library default algorithms", file=sys.stderr)
+            tuning.disable_gemm_tuning()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
