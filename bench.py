@@ -451,6 +451,7 @@ def main():
     ap.add_argument("--gemm-tune", default=None, metavar="CSV", help="time the library's GEMM candidates for every shape of this run and write the picks to CSV (offline step)")
     ap.add_argument("--gemm-tune-rotate", type=int, default=None, metavar="MB", help="with --gemm-tune: rotate the operands through a buffer of this size (cold-cache timing)")
     ap.add_argument("--gemm-picks", default=None, metavar="CSV", help="look up this results file instead of gmlm_amd/tunable/gfx950.csv")
+    ap.add_argument("--no-hip-graph", action="store_true", help="cornell / chameleon: run eagerly (they replay hipGraphs by default)")
     ap.add_argument("--hip-graph", action="store_true", help="replay the static-shape regions (GNN blocks, cross-attention + head) from hipGraphs: for the launch-bound small workloads")
     ap.add_argument("--ring", action="store_true", help="N > 1: CrossAttention through the ring K|V exchange instead of the K|V all-gather")
     ap.add_argument("--no-ring", action="store_true")
@@ -535,6 +536,8 @@ def main():
     ei = data["edge_index"].to(dev)
     tokens = gmlm_amd.TokenizedTexts.from_mask(ids[lo:hi].to(dev), am[lo:hi].to(dev))
     n_active_total = int(data["active"].sum())
+    if args.workload in ("cornell", "chameleon") and not distributed and not args.no_hip_graph:
+        args.hip_graph = True                        # the launch-bound small workloads replay their static regions by default
     if args.hip_graph:
         if distributed:
             raise SystemExit("--hip-graph is single-GPU")
