@@ -150,11 +150,13 @@ class _Linear(torch.autograd.Function):
     GEMM epilogue) instead of autograd running a separate add kernel."""
 
     @staticmethod
-    def forward(ctx, x, wc, bc, residual, *masters):
+    def forward(ctx, x, wc, bc, residual, bias_grad, *masters):
+        """``bias_grad`` False: ``bc`` is added but its masters are not among ``masters`` (their gradient is produced
+        elsewhere: ops.AttentionQKV returns the fused QKV bias gradient itself, from inside its backward kernel)."""
         ctx.save_for_backward(x, wc)
         ctx.masters = masters
-        ctx.n_w = len(masters) if bc is None else len(masters) // 2
-        ctx.has_bias = bc is not None
+        ctx.has_bias = bc is not None and bias_grad
+        ctx.n_w = len(masters) // 2 if ctx.has_bias else len(masters)
         y = torch.nn.functional.linear(x, wc, bc)
         return (y, x.view_as(x)) if residual else y
 
@@ -173,36 +175,38 @@ class _Linear(torch.autograd.Function):
                 dres2 = dxres.reshape(-1, x.shape[-1])
                 dx = (dres2.addmm_(dy2, wc) if dres2.is_contiguous() else torch.addmm(dres2, dy2, wc)).view(x.shape)
         grads = [None] * len(masters)
-        need = ctx.needs_input_grad[4:]
+        need = ctx.needs_input_grad[5:]
         if any(need[:n_w]):
             dw = _splitk_wgrad(dy2, x2, keep_fp32=True)
             for i, (m, g) in enumerate(zip(masters[:n_w], dw.split([m.shape[0] for m in masters[:n_w]], 0))):
                 if need[i]:
                     grads[i] = g if g.dtype == m.dtype else g.to(m.dtype)
         if ctx.has_bias and any(need[n_w:]):
-            # the consumer may already hold the column sums (ops.AttentionQKV's short-sequence backward forms them in-kernel)
-            db = getattr(dy, "_gmlm_colsum", None)
-            if db is None or db.shape != (dy2.shape[-1],):
-                db = dy2.sum(0, dtype=torch.float32)
+            db = dy2.sum(0, dtype=torch.float32)
             for i, (m, g) in enumerate(zip(masters[n_w:], db.split([m.shape[0] for m in masters[n_w:]], 0))):
                 if need[n_w + i]:
                     grads[n_w + i] = g if g.dtype == m.dtype else g.to(m.dtype)
-        return (dx, None, None, None, *grads)
+        return (dx, None, None, None, None, *grads)
 
 
-def _mm(x, wc, bc, masters, residual=False):
+def _mm(x, wc, bc, masters, residual=False, bias_grad=True):
     with torch.autocast("cuda", enabled=False):
-        return _Linear.apply(x, wc, bc, residual, *masters)
+        return _Linear.apply(x, wc, bc, residual, bias_grad, *masters)
 
 
 def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None):
     pdim = h.shape[-1]
     d = pdim // heads
-    qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv, residual=True)                 # [B, L, 3P] or packed [T, 3P]
     scale = d ** -0.5
     if d in (64, 96):
-        ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len, pair_count)
+        # the fused projection adds the Q|K|V biases; their GRADIENT (the column sums of dqkv) is returned by the attention
+        # operator, which can form it inside its backward kernel (ops.AttentionQKV): an explicit autograd edge
+        # bias master -> attention op, no side channel between the two backward functions
+        qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv[:3], residual=True, bias_grad=False)   # [B, L, 3P] or packed [T, 3P]
+        ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len, pair_count,
+                                bias_masters=lw.m_qkv[3:])
     else:
+        qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv, residual=True)
         ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
                                 training)
     a = ops.bias_res_layernorm(_mm(ctx, lw.wo, None, lw.m_wo), lw.bo, h_res, lw.ln1w, lw.ln1b, eps, False, p_hidden, training)

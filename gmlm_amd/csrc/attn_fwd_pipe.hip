@@ -475,12 +475,13 @@ static int launch_pipe(dim3 grid2, hipStream_t st, const AttnParams& p0) {
   p.grid_q = grid2.x; p.grid_pairs = grid2.y;
   const dim3 grid(grid2.x * grid2.y);
   constexpr int kLds = 2 * NB * Img<D>::TILE;
-  static bool attr_set = false;                          // > 64 KiB of dynamic LDS needs the attribute once per instantiation
-  if (!attr_set) {
+  static PerDeviceOnce once;                             // > 64 KiB of dynamic LDS needs the attribute once per instantiation and device
+  const int rc = once([&]() -> int {
     GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<D, NW, true, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
     GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_pipe_kernel<D, NW, false, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
-    attr_set = true;
-  }
+    return GMLM_OK;
+  });
+  if (rc != GMLM_OK) return rc;
   if (p.drop_thresh) attn_fwd_pipe_kernel<D, NW, true, NB><<<grid, NW * 64, kLds, st>>>(p);
   else attn_fwd_pipe_kernel<D, NW, false, NB><<<grid, NW * 64, kLds, st>>>(p);
   return GMLM_OK;

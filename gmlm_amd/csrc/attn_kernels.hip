@@ -951,16 +951,17 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
 #endif
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && (cu_seqlens ? max_len : lk) <= 128 && b * h >= 512) {
     // short sequences, enough of them to fill the chip: Q / K / V resident in LDS, one barrier (attn_fwd_short_kernel)
-    static bool attr_set = false;
+    static PerDeviceOnce once;
     auto lds_of = [](int r) { return (size_t)3 * r * 64 * sizeof(bf16_t); };        // dense swizzled Q / K / V images
-    if (!attr_set) {
+    rc = once([&]() -> int {
 #define GMLM_SHORT_ATTR(RR)                                                                                                        \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, false, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR)));
       GMLM_SHORT_ATTR(32) GMLM_SHORT_ATTR(64) GMLM_SHORT_ATTR(96) GMLM_SHORT_ATTR(128)
 #undef GMLM_SHORT_ATTR
-      attr_set = true;
-    }
+      return GMLM_OK;
+    });
+    if (rc != GMLM_OK) return rc;
     const int64_t rk_ = cu_seqlens ? max_len : lk, rmax = rows_q > rk_ ? rows_q : rk_;
     const int top = (int)((rmax + 31) / 32) * 32;
 #define GMLM_SHORT_LAUNCH(RR)                                                                                                      \
@@ -1038,16 +1039,17 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed; p.seed_dev = seed_dev;
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && rows_k <= 128 && b * h >= 512) {
     // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace
-    static bool attr_set = false;
+    static PerDeviceOnce once;
     auto lds_of = [](int r) { return (size_t)4 * r * (64 + 8) * sizeof(bf16_t) + 2 * r * sizeof(float) + 2 * r * sizeof(bf16_t); };   // K, V, Q, dO images + lse, delta + bias-gradient coefficients
-    if (!attr_set) {
+    rc = once([&]() -> int {
 #define GMLM_SHORT_ATTR(RR)                                                                                                        \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
       GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, false, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR)));
       GMLM_SHORT_ATTR(32) GMLM_SHORT_ATTR(64) GMLM_SHORT_ATTR(96) GMLM_SHORT_ATTR(128)
 #undef GMLM_SHORT_ATTR
-      attr_set = true;
-    }
+      return GMLM_OK;
+    });
+    if (rc != GMLM_OK) return rc;
     const int64_t rmax = rows_q > rows_k ? rows_q : rows_k;
     const int top = (int)((rmax + 31) / 32) * 32;
 #define GMLM_SHORT_LAUNCH(RR)                                                                                                      \

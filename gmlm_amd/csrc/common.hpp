@@ -7,6 +7,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "../../include/gmlm_hip.h"
 
 namespace gmlm {
@@ -40,6 +42,23 @@ void set_error(const char* fmt, ...);
       return GMLM_ELAUNCH;                                                              \
     }                                                                                   \
   } while (0)
+
+// Kernel attributes (dynamic LDS beyond 64 KiB) are a property of (function, device): set them once per DEVICE, under a lock,
+// so that the library is safe to call from several host threads and from one process that drives several GPUs.  The only
+// state kept is "device d has been initialised" (write-once bits).
+struct PerDeviceOnce {
+  std::mutex mu;
+  uint64_t done = 0;
+  template <typename F> int operator()(F&& init) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    std::lock_guard<std::mutex> guard(mu);
+    if (dev >= 0 && dev < 64 && ((done >> dev) & 1ull)) return GMLM_OK;
+    const int rc = init();
+    if (rc == GMLM_OK && dev >= 0 && dev < 64) done |= 1ull << dev;
+    return rc;
+  }
+};
 
 inline hipStream_t as_stream(gmlm_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -308,11 +308,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const float* __restrict__ word, const float* __restrict__ pos,
                                                              const float* __restrict__ type0, const int64_t* __restrict__ tok,
                                                              const int64_t* __restrict__ pos_ids, int64_t rows, int p, int64_t vocab,
-                                                             int64_t npos, T* __restrict__ out) {
+                                                             int64_t npos, T* __restrict__ out, int32_t* __restrict__ bad_flag) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < rows; r += (int64_t)gridDim.x * 4) {
     int64_t tv = tok[r], pv = pos_ids[r];
-    tv = tv < 0 ? 0 : (tv >= vocab ? vocab - 1 : tv);          // ids are validated by the caller; never read out of bounds
+    // F.embedding raises on an id outside its table; a kernel cannot: it never reads out of bounds (the id is clamped) and
+    // REPORTS the violation through *bad_flag, which the caller inspects (wave-uniform condition: one lane writes)
+    if ((tv < 0 || tv >= vocab || pv < 0 || pv >= npos) && bad_flag && lane == 0) *bad_flag = 1;
+    tv = tv < 0 ? 0 : (tv >= vocab ? vocab - 1 : tv);
     pv = pv < 0 ? 0 : (pv >= npos ? npos - 1 : pv);
     const float* wr = word + tv * p;
     const float* pr = pos + pv * p;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const float* __restr
 
 extern "C" int gmlm_embed_sum_fwd(const float* word, const float* pos, const float* type0, const int64_t* tok,
                                   const int64_t* pos_ids, int64_t rows, int64_t p, int64_t vocab, int64_t npos, void* out,
-                                  int dtype, gmlm_stream_t stream) {
+                                  int dtype, int32_t* bad_flag, gmlm_stream_t stream) {
   using namespace gmlm;
   GMLM_REQUIRE(rows >= 0 && p > 0 && p % 4 == 0 && vocab > 0 && npos > 0, "embed_sum_fwd: bad sizes (p must be a multiple of 4)");
   GMLM_REQUIRE(dtype == GMLM_F32 || dtype == GMLM_BF16, "embed_sum_fwd: dtype must be GMLM_F32 or GMLM_BF16");
@@ -345,9 +348,9 @@ extern "C" int gmlm_embed_sum_fwd(const float* word, const float* pos, const flo
   GMLM_REQUIRE(aligned16(word) && aligned16(pos) && aligned16(type0) && aligned16(out), "embed_sum_fwd: tables / output must be 16-byte aligned");
   const unsigned grid = (unsigned)(cdiv(rows, 4) < 65536 ? cdiv(rows, 4) : 65536);
   if (dtype == GMLM_F32)
-    embed_sum_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (float*)out);
+    embed_sum_fwd_kernel<float><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (float*)out, bad_flag);
   else
-    embed_sum_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (bf16_t*)out);
+    embed_sum_fwd_kernel<bf16_t><<<grid, 256, 0, as_stream(stream)>>>(word, pos, type0, tok, pos_ids, rows, (int)p, vocab, npos, (bf16_t*)out, bad_flag);
   GMLM_LAUNCH_CHECK();
   return GMLM_OK;
 }

@@ -124,15 +124,21 @@ class _HaloExchange(torch.autograd.Function):
     """x [n_local, ...] -> [n_local + n_halo, ...]: owned rows, then the remote rows this rank's edges reference.
 
     The receive lands directly in the tail of the output buffer (no torch.cat pass).  With a device-capable backend
-    (RCCL) the all-to-all-v is started asynchronously and the wait is deferred to ``PartitionContext.wait_halo()``:
-    the caller runs the work that does not need the halo rows (the root GEMM x W_root of RGCNConv) in between, so
-    the exchange of layer k hides under it."""
+    (RCCL) the all-to-all-v is started asynchronously and the wait is deferred to ``PartitionContext.halo_ready()`` /
+    ``wait_halo()``: the caller runs the work that does not need the halo rows (the root GEMM x W_root of RGCNConv) in
+    between, so the exchange of layer k hides under it.
+
+    Backward mirrors that.  ``halo_ready`` is an autograd node of its own (``_HaloReady``) created AFTER the root GEMM,
+    so in backward it runs BEFORE the root GEMM's backward: it starts the reverse all-to-all-v of the halo rows'
+    gradients asynchronously; the root GEMM's data- and weight-gradient GEMMs run meanwhile; this node's backward, which
+    runs last, waits and applies the returned rows.  Without a ``halo_ready`` node (plain ``wait_halo()``) the reverse
+    exchange is done here, synchronously."""
 
     @staticmethod
-    def forward(ctx, x, part, defer):
+    def forward(ctx, x, part, defer, token):
         plan, group = part.plan, part.group
         n = plan.n_local
-        ctx.part = part
+        ctx.part, ctx.token = part, token
         send = x.index_select(0, part.send_idx).contiguous()
         out = x.new_empty((n + plan.n_halo,) + tuple(x.shape[1:]))
         out[:n] = x
@@ -150,11 +156,14 @@ class _HaloExchange(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         part = ctx.part
-        plan, group = part.plan, part.group
+        plan = part.plan
         n = plan.n_local
-        g_halo = _staged(g[n:].contiguous(), group)
-        back = g_halo.new_empty((part.send_idx.numel(),) + tuple(g.shape[1:]))
-        dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group)
+        started = part._halo_bwd.pop(ctx.token, None)
+        if started is None:
+            started = _start_halo_backward(part, g)
+        work, back, _keep = started
+        if work is not None:
+            work.wait()
         gx = g[:n].clone()
         back = back.to(g.device)
         # deterministic: a row goes to a given peer at most once, so each peer's slice has unique targets (its adds
@@ -164,7 +173,37 @@ class _HaloExchange(torch.autograd.Function):
             if cnt:
                 gx.index_add_(0, part.send_idx[off:off + cnt], back[off:off + cnt])
             off += cnt
-        return gx, None, None
+        return gx, None, None, None
+
+
+def _start_halo_backward(part, g):
+    """Reverse all-to-all-v of the halo rows' gradients: (work | None, receive buffer, keep-alive)."""
+    plan, group = part.plan, part.group
+    g_halo = _staged(g[plan.n_local:].contiguous(), group)
+    back = g_halo.new_empty((part.send_idx.numel(),) + tuple(g.shape[1:]))
+    if g.is_cuda and _is_gloo(group):                         # rehearsal path: synchronous, staged through the host
+        dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group)
+        return None, back, g_halo
+    work = dist.all_to_all_single(back, g_halo, plan.send_counts, plan.recv_counts, group=group, async_op=True)
+    return work, back, g_halo
+
+
+class _HaloReady(torch.autograd.Function):
+    """Identity on the [n_local + n_halo, ...] buffer that (forward) waits for the halo rows and (backward) STARTS the
+    reverse exchange of their gradients; see ``_HaloExchange``."""
+
+    @staticmethod
+    def forward(ctx, xh, part, token):
+        part.wait_halo()
+        ctx.part, ctx.token = part, token
+        return xh.view_as(xh)
+
+    @staticmethod
+    def backward(ctx, g):
+        part = ctx.part
+        if part.plan.n_halo or any(part.plan.send_counts):
+            part._halo_bwd[ctx.token] = _start_halo_backward(part, g)
+        return g, None, None
 
 
 class _AllGatherRows(torch.autograd.Function):
@@ -270,6 +309,8 @@ class _RingAttention(torch.autograd.Function):
         dcur = torch.zeros(b, mx, 2 * c, dtype=acc_t, device=q.device)            # gradient accumulator that travels with the block
         dq = torch.zeros(b, n, c, dtype=acc_t, device=q.device)
         nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+        lse32 = lse.to(torch.promote_types(lse.dtype, torch.float32))
+        pend_d, dnxt = None, None
         for s in range(world):
             owner = (rank - s) % world
             pend, nxt = None, None
@@ -277,18 +318,25 @@ class _RingAttention(torch.autograd.Function):
                 nxt = torch.empty_like(cur)
                 pend = _exchange(cur, nxt, nxt_rank, prv_rank, group)
             kv_len = torch.full((b,), sizes[owner], dtype=torch.int32, device=q.device)
-            dq_j, dk_j, dv_j = block.bwd(q, cur[..., :c], cur[..., c:], out, dout, lse.to(torch.promote_types(lse.dtype, torch.float32)), kv_len, seed + owner)
+            dq_j, dk_j, dv_j = block.bwd(q, cur[..., :c], cur[..., c:], out, dout, lse32, kv_len, seed + owner)
+            # the accumulator of THIS block left the previous rank while this block's arithmetic ran (posted at the end
+            # of the previous step): its hop is hidden, only now is it needed
+            if pend_d is not None:
+                pend_d.wait()
+                dcur = dnxt
             dq += dq_j.to(acc_t)
             dcur[..., :c] += dk_j.to(acc_t)
             dcur[..., c:] += dv_j.to(acc_t)
             if pend is not None:
                 pend.wait()
-            # the accumulator follows its block (after the last step it makes the closing hop home)
+            # the accumulator follows its block (after the last step it makes the closing hop home); every rank posts
+            # K|V(s), dK|dV(s), K|V(s+1), ... in the same order
             dnxt = torch.empty_like(dcur)
-            _exchange(dcur, dnxt, nxt_rank, prv_rank, group).wait()
-            dcur = dnxt
+            pend_d = _exchange(dcur, dnxt, nxt_rank, prv_rank, group)
             if nxt is not None:
                 cur = nxt
+        pend_d.wait()
+        dcur = dnxt
         return dq.to(q.dtype), dcur[:, :kv.shape[1]].to(kv.dtype), None, None, None, None
 
 
@@ -317,19 +365,28 @@ class GradBuckets:
     The gradients of the replicated parameters live as VIEWS inside a few flat fp32 buffers (``prepare()`` installs
     the views and zeroes the buffers with one memset each: it replaces ``zero_grad``).  A post-accumulate hook counts
     a bucket's gradients down; when the last one is final the bucket's all-reduce starts, asynchronously, while
-    backward continues with the earlier layers (buckets are filled in reverse parameter order).  Buckets are always
-    LAUNCHED in bucket order, so every rank issues the same collective sequence even when a rank's gradients become
-    final at different times or not at all (a rank without active text nodes never sees a PLM gradient: it launches
-    those buckets in ``finish()``).
+    backward continues with the earlier layers (buckets are filled in reverse parameter order).
+
+    Ordering.  The bucket all-reduces run on their OWN process group / communicator (``part.grad_group``), not on the
+    group that carries backward's other collectives (GraphNorm statistics, halo all-to-all, RGCN basis reducer, K|V
+    reduce-scatter / ring).  WHEN a bucket becomes final depends on the rank: a rank without active text nodes never
+    sees a PLM gradient and launches those buckets in ``finish()``, i.e. after the GNN-backward collectives that an
+    active rank issues after them.  On a shared communicator that is a cross-rank order mismatch (gloo: an
+    EnforceNotMet abort; RCCL: a hang or silent corruption); on a communicator of their own the buckets only have to
+    be ordered among themselves, and they are: always LAUNCHED in bucket order.
 
     Which parameters take part is a collective decision made on the first step (``finish()`` votes with MAX on "got a
     gradient"): a parameter without a gradient on ANY rank (dead ``residual_proj3``, BERT pooler) keeps ``grad =
-    None`` like the single-GPU run, and is not waited for afterwards.  If a parameter outside that set ever receives
-    a gradient, the set is re-learned (that step reduces it separately)."""
+    None`` like the single-GPU run, and is not waited for afterwards.  Every later step repeats the vote (one small
+    all-reduce): a parameter of the learned set that got a gradient on NO rank in this step goes back to ``grad =
+    None`` for this step (AdamW then skips it exactly like the single-GPU / reference run: e.g. the PLM during a
+    pre-training step), and if a parameter outside the set receives a gradient the set is re-learned (that step reduces
+    it separately)."""
 
     def __init__(self, part, module, bucket_bytes: int = 256 << 20):
         from .nn import RGCNConv
         self.part = part
+        self.group = part.grad_group()                          # collective: every rank builds its GradBuckets at the same point
         skip = set()
         for m in module.modules():                              # reduced inside backward as composed relation weights
             if isinstance(m, RGCNConv):
@@ -390,11 +447,10 @@ class GradBuckets:
     def _launch_ready(self, force=False):
         while self.next_launch < len(self.buckets) and (force or self.pending[self.next_launch] == 0):
             flat = self.flats[self.next_launch]
-            gloo = _is_gloo(self.part.group)
-            if flat.is_cuda and gloo:                           # rehearsal: synchronous, staged
-                self.part.all_reduce_sum(flat)
+            if flat.is_cuda and _is_gloo(self.group):           # rehearsal: synchronous, staged
+                self.part.all_reduce_sum(flat, group=self.group)
             else:
-                self._works.append(dist.all_reduce(flat, group=self.part.group, async_op=True))
+                self._works.append(dist.all_reduce(flat, group=self.group, async_op=True))
             self.next_launch += 1
 
     def _on_grad(self, p):
@@ -416,29 +472,29 @@ class GradBuckets:
         for w in self._works:
             w.wait()
         self._works = []
+        # one vote per step: "some rank has a gradient for parameter i" (after backward: every rank is at the same
+        # point of the main group's collective sequence)
+        has = torch.tensor([1.0 if f else 0.0 for f in self.fired])
+        if has.numel():
+            part.all_reduce_max(has)
+        has = [bool(v > 0.5) for v in has.tolist()]
         if self.expected is None:
-            # learning step: vote on "some rank has a gradient for it"; the others go back to grad = None
-            has = torch.tensor([1.0 if f else 0.0 for f in self.fired])
-            if has.numel():
-                part.all_reduce_max(has)
-            self.expected = [bool(v > 0.5) for v in has.tolist()]
+            # learning step: the parameters without a gradient anywhere go back to grad = None
+            self.expected = has
             for p, keep in zip(self.params, self.expected):
                 if not keep:
                     p.grad = None
             return
-        # steady state: did any rank get a gradient for a parameter outside the learned set?
-        stray = [i for i, p in enumerate(self.params) if not self.expected[i] and p.grad is not None]
-        flag = torch.tensor([1.0 if stray else 0.0])
-        part.all_reduce_max(flag)
-        if float(flag) > 0.5:
-            has = torch.tensor([1.0 if (not e and p.grad is not None) else 0.0 for p, e in zip(self.params, self.expected)])
-            part.all_reduce_max(has)
-            for i, v in enumerate(has.tolist()):
-                if v > 0.5:
-                    p = self.params[i]
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                    part.all_reduce_sum(p.grad)
+        stray = False
+        for i, (p, got) in enumerate(zip(self.params, has)):
+            if self.expected[i] and not got:
+                p.grad = None                                   # no rank produced it in THIS step: same as the single-GPU run
+            elif got and not self.expected[i]:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                part.all_reduce_sum(p.grad)                     # outside the learned set: reduced on its own, same order on every rank
+                stray = True
+        if stray:
             self.expected = None                                # learn the set again on the next step
 
     def remove(self):
@@ -460,6 +516,9 @@ class PartitionContext:
         self.csr = None
         self.use_ring = False            # CrossAttention: ring K|V exchange instead of the K|V all-gather
         self._halo_pending = []
+        self._halo_bwd = {}              # token -> reverse exchange started by _HaloReady.backward, consumed by _HaloExchange.backward
+        self._halo_token = None
+        self._grad_group = None
 
     def build_csr(self, num_relations: int):
         from .graph import build_rel_csr
@@ -470,10 +529,29 @@ class PartitionContext:
         return self.csr
 
     # -- exchange steps ---------------------------------------------------------------------
+    def grad_group(self):
+        """Process group (communicator) of the gradient-bucket all-reduces: the same ranks as ``group``, a collective
+        sequence of its own (see ``GradBuckets``).  Creating it is a collective over the default group, so every rank
+        calls this at the same point (``grad_buckets(model)`` on the first step)."""
+        if self._grad_group is None:
+            ranks = dist.get_process_group_ranks(self.group)
+            self._grad_group = dist.new_group(ranks=ranks, backend=dist.get_backend(self.group))
+        return self._grad_group
+
     def with_halo(self, x: torch.Tensor, defer: bool = False) -> torch.Tensor:
         """``defer=True``: the exchange is only STARTED; rows [n_local, n_local + n_halo) of the result are valid
-        after ``wait_halo()`` (the caller puts independent work in between)."""
-        return _HaloExchange.apply(x, self, defer)
+        after ``halo_ready(result)`` (the caller puts independent work in between and uses what ``halo_ready``
+        returns: that node also overlaps the BACKWARD exchange with the backward of the work in between) or after a
+        plain ``wait_halo()`` (backward exchange synchronous)."""
+        token = object()
+        out = _HaloExchange.apply(x, self, defer, token)
+        self._halo_token = token if defer else None          # one exchange in flight at a time (the layers are sequential)
+        return out
+
+    def halo_ready(self, xh: torch.Tensor) -> torch.Tensor:
+        """Wait for the exchange started by the last ``with_halo(..., defer=True)`` and return the buffer."""
+        token, self._halo_token = self._halo_token, None
+        return _HaloReady.apply(xh, self, token if token is not None else object())
 
     def wait_halo(self) -> None:
         while self._halo_pending:
@@ -483,21 +561,22 @@ class PartitionContext:
     def ring_attention(self, q: torch.Tensor, kv: torch.Tensor, num_heads: int, block, seed: int = 0) -> torch.Tensor:
         return _RingAttention.apply(q, kv, self, num_heads, block, seed)
 
-    def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
+    def _all_reduce(self, t: torch.Tensor, op, group=None) -> torch.Tensor:
         """In-place all-reduce of ``t`` wherever it lives: gloo has no device collectives (device tensors are staged
         through the host: tests / 1-GPU rehearsals), RCCL has no host collectives (small host tensors are staged
         through the device)."""
-        gloo = _is_gloo(self.group)
+        group = self.group if group is None else group
+        gloo = _is_gloo(group)
         if t.is_cuda == (not gloo):
-            dist.all_reduce(t, op=op, group=self.group)
+            dist.all_reduce(t, op=op, group=group)
         else:
             c = t.cpu() if gloo else t.to(self.device)
-            dist.all_reduce(c, op=op, group=self.group)
+            dist.all_reduce(c, op=op, group=group)
             t.copy_(c)
         return t
 
-    def all_reduce_sum(self, t: torch.Tensor) -> torch.Tensor:
-        return self._all_reduce(t, dist.ReduceOp.SUM)
+    def all_reduce_sum(self, t: torch.Tensor, group=None) -> torch.Tensor:
+        return self._all_reduce(t, dist.ReduceOp.SUM, group)
 
     def all_reduce_min(self, t: torch.Tensor) -> torch.Tensor:
         """MIN over ranks (collective yes / no decisions)."""
@@ -521,11 +600,13 @@ class PartitionContext:
         return gb
 
     def all_reduce_grads(self, module: torch.nn.Module, bucket_bytes: int = 256 << 20) -> None:
-        """Sum replicated parameter gradients over ranks in a few large flat buckets (xGMI is per-link
-        bound: few big messages).  Which parameters take part is decided collectively: a parameter that has a
-        gradient on SOME rank is summed (ranks without one contribute zeros); a parameter without a gradient on
-        ANY rank (the dead ``residual_proj3`` branch, the unused BERT pooler) keeps ``grad = None`` exactly like
-        the single-GPU / reference run, so AdamW neither decays it nor creates state for it."""
+        """After-backward form (no overlap) for callers that did not ``grad_buckets(module).prepare()`` before backward:
+        sums the replicated parameter gradients over ranks in a few large flat fp32 buckets (xGMI is per-link bound: few
+        big messages).  Which parameters take part is decided collectively: a parameter that has a gradient on SOME
+        rank is summed (ranks without one contribute zeros); a parameter without a gradient on ANY rank (the dead
+        ``residual_proj3`` branch, the unused BERT pooler) keeps ``grad = None`` exactly like the single-GPU /
+        reference run, so AdamW neither decays it nor creates state for it.  The gradients are moved INTO the flat
+        reduce buffer with one multi-tensor copy and then re-pointed at it (views): no ``torch.cat``, no copy back."""
         params = [p for p in module.parameters()
                   if p.requires_grad and not getattr(p, "_gmlm_grad_reduced", False)]   # else: frozen, or summed inside backward (RGCN bases)
         has = torch.tensor([0.0 if p.grad is None else 1.0 for p in params])
@@ -537,22 +618,24 @@ class PartitionContext:
             nonlocal bucket, size
             if not bucket:
                 return
-            flat = torch.cat([g.reshape(-1).float() for g in bucket])
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=bucket[0].device)
+            views, off = [], 0
+            for p in bucket:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            have = [(v, p.grad) for v, p in zip(views, bucket) if p.grad is not None]
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
             self.all_reduce_sum(flat)
-            off = 0
-            for g in bucket:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+            for p, v in zip(bucket, views):
+                p.grad = v if p.dtype == torch.float32 else v.to(p.dtype)
             bucket, size = [], 0
 
         for p, h in zip(params, has.tolist()):
             if h < 0.5:
                 continue                      # no rank has a gradient for it
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            bucket.append(p.grad)
-            size += p.grad.numel() * 4
+            bucket.append(p)
+            size += p.numel() * 4
             if size >= bucket_bytes:
                 flush()
         flush()

@@ -35,6 +35,14 @@ class TokenizedTexts:
         self.input_ids = input_ids.to(torch.int32).contiguous()
         self.lens = lens.to(torch.int32).contiguous()
         self.lens_host = self.lens.cpu()
+        self._ids_checked = None          # (vocab, max positions) the ids were validated against (ops.check_embed_ids)
+        self._source = None               # the text list these ids were made from (GraphTextLM.tokenize)
+
+    def check_ids(self, vocab: int, npos: int) -> None:
+        """Raise like F.embedding / HF BERT would on an out-of-range token id or an over-long sequence; once per table size."""
+        if self._ids_checked != (vocab, npos):
+            ops.check_embed_ids(self.input_ids, self.lens, vocab, npos)
+            self._ids_checked = (vocab, npos)
 
     @classmethod
     def from_mask(cls, input_ids: torch.Tensor, attention_mask: torch.Tensor):
@@ -120,7 +128,7 @@ class GraphTextLM(nn.Module):
         if self.dist is not None:
             x = self.dist.with_halo(x, defer=True)                    # [n_local + n_halo, F]; halo rows land under the root GEMM
         z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None,
-                             self.dist.wait_halo if self.dist is not None else None)                 # [n, out] in cd
+                             self.dist.halo_ready if self.dist is not None else None)                # [n, out] in cd
         cd = x.dtype
         n_total = self.dist.n_total if self.dist is not None else z.size(0)
         if n_total > 1:                                               # main.py:273 guard
@@ -158,19 +166,28 @@ class GraphTextLM(nn.Module):
     # ------------------------------------------------------------------------------------------
     def tokenize(self, all_node_texts) -> TokenizedTexts:
         """Tokenise every node text once on the host (same tokenizer call as main.py:342-345) and keep
-        the ids on the device.  The cache is keyed by the identity of the text list AND its content (length +
-        hash of the strings: ~1 ms per 10k texts), so a list mutated in place is re-tokenised."""
+        the ids on the device.  The cache is keyed by the identity of the text list, its length and a 65-string sample of
+        its content, so a list that is appended to, truncated or rewritten is re-tokenised; a caller that edits single
+        strings of the same list in place between steps calls ``clear_caches()`` (the reference re-tokenises every step,
+        main.py:342: its texts are read-only during training)."""
         if isinstance(all_node_texts, TokenizedTexts):
             return all_node_texts
-        key = (id(all_node_texts), len(all_node_texts), hash(tuple(all_node_texts)))
-        hit = self._tokens.get(key)
-        if hit is not None and hit[1] is all_node_texts:
-            return hit[0]
+        # Per step the check is O(1) + a fixed-size sample: same list object, same length, same strings at 64 evenly spaced
+        # positions (compared by identity first: an unchanged list holds the very same str objects).  The full content hash
+        # (O(N): ~17 ms at arxiv size, ~1 s at 10M nodes) is taken only when the list is first seen or the sample moved.
+        n = len(all_node_texts)
+        hit = self._tokens.get(id(all_node_texts))
+        if hit is not None and hit[1] is all_node_texts and hit[2] == n:
+            probe = hit[3]
+            if all(all_node_texts[i] is t or all_node_texts[i] == t for i, t in probe):
+                return hit[0]
         enc = self.plm_tokenizer(list(all_node_texts), padding=True, truncation=True, max_length=self.plm_max_length,
                                  return_tensors="pt")
         dev = self.gnn_mask_token_embed.device
         tt = TokenizedTexts.from_mask(enc["input_ids"].to(dev), enc["attention_mask"].to(dev))
-        self._tokens = {key: (tt, all_node_texts)}
+        step = max(1, n // 64)
+        probe = [(i, all_node_texts[i]) for i in range(0, n, step)][:64] + ([(n - 1, all_node_texts[n - 1])] if n else [])
+        self._tokens = {id(all_node_texts): (tt, all_node_texts, n, probe)}
         return tt
 
     def clear_caches(self):
@@ -212,6 +229,8 @@ class GraphTextLM(nn.Module):
 
         self.active_index = to_dev(idx_h)                             # for the caller's loss gather (no mask indexing sync)
         cd = self._cd()
+        ecfg = self.plm_encoder.config
+        tokens.check_ids(ecfg.vocab_size, ecfg.max_position_embeddings)      # one sync per token set, not per step
         lens_h = tokens.lens_host[idx_h]
         # length-bucketed micro-batches: every active node is encoded independently and scattered by its own
         # index, so the order is free; sorting by token count keeps the padding of each micro-batch small

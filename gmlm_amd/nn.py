@@ -143,8 +143,9 @@ class RGCNConv(nn.Module):
         hipBLASLt GEMMs: bias + x root, then += H W_cat; no fp32 staging passes over [n, out]).
 
         Node partition: rows [n, n_src) of x are halo rows whose all-to-all may still be in flight; the root GEMM
-        (owned rows only) and the basis composition run first, ``halo_wait()`` is called right before the
-        aggregation, so the exchange hides under them."""
+        (owned rows only) and the basis composition run first, ``x = halo_wait(x)`` right before the aggregation
+        (``PartitionContext.halo_ready``), so the exchange hides under them; in backward the same node starts the
+        reverse exchange ahead of the root GEMM's backward."""
         in_pad = x.shape[1] - self.in_channels
         n = csr.num_nodes
         with torch.autocast("cuda", enabled=False):
@@ -152,7 +153,7 @@ class RGCNConv(nn.Module):
             root = self.root if not in_pad else F.pad(self.root, (0, 0, 0, in_pad))
             out = torch.addmm(self.bias.to(x.dtype), x[:n], root.to(x.dtype))
         if halo_wait is not None:
-            halo_wait()
+            x = halo_wait(x)
         h = ops.RGCNAggregate.apply(x, csr)                                   # [n, R_a*(in+pad)]
         with torch.autocast("cuda", enabled=False):
             return out.addmm_(h, w)

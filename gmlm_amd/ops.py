@@ -411,7 +411,10 @@ class AttentionQKV(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len, pair_count=None):
+    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len, pair_count=None, *bias_masters):
+        """``bias_masters``: optional (q, k, v) bias parameters of the fused projection that produced ``qkv``.  Their values
+        are not read (the projection has added them); they are inputs so that backward can RETURN their gradient, the
+        column sums of dqkv, which the short-sequence kernel forms in-kernel (otherwise one reduction pass here)."""
         _cuda(qkv)
         qkv = qkv.contiguous()
         packed = cu_seqlens is not None
@@ -434,12 +437,14 @@ class AttentionQKV(torch.autograd.Function):
                                            _stream()), "gmlm_attention_fwd")
         ctx.save_for_backward(qkv, out, lse, kv_len, cu_seqlens)
         ctx.cfg = (h, float(scale), float(p), seed, int(max_len), b, l, flops)
+        ctx.bias_shapes = [(m.shape[0], m.dtype) for m in bias_masters]
         return out
 
     @staticmethod
     def backward(ctx, gout):
         qkv, out, lse, kv_len, cu_seqlens = ctx.saved_tensors
         h, scale, p, seed, max_len, b, l, flops = ctx.cfg
+        want_db = bool(ctx.bias_shapes) and any(ctx.needs_input_grad[9:])
         hd3 = qkv.shape[-1]
         hd = hd3 // 3
         d = hd // h
@@ -451,7 +456,7 @@ class AttentionQKV(torch.autograd.Function):
         # short-sequence path (one launch per (sequence, head): same condition as the C entry): the column sums of dqkv --
         # the bias gradient of the fused QKV projection that produced qkv -- come out of the kernel as well
         rows = max_len if cu_seqlens is not None else l
-        fused_db = qkv.dtype == torch.bfloat16 and d == 64 and rows <= 128 and b * h >= 512
+        fused_db = want_db and qkv.dtype == torch.bfloat16 and d == 64 and rows <= 128 and b * h >= 512
         part = db = None
         if fused_db:
             part = _ws(4 * b * hd3, qkv.device).view(torch.float32)
@@ -463,9 +468,13 @@ class AttentionQKV(torch.autograd.Function):
                                            hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _ptr(part), _ptr(db),
                                            _stream()),
                   "gmlm_attention_bwd")
-        if db is not None:
-            dqkv._gmlm_colsum = db            # picked up by the producer's backward (bert._Linear) instead of a pass over dqkv
-        return dqkv, None, None, None, None, None, None, None, None
+        dbs = ()
+        if want_db:
+            if db is None:
+                db = dqkv.reshape(-1, hd3).sum(0, dtype=torch.float32)
+            dbs = tuple(g if g.dtype == dt_ else g.to(dt_)
+                        for g, (_, dt_) in zip(db.split([n_ for n_, _ in ctx.bias_shapes], 0), ctx.bias_shapes))
+        return (dqkv, None, None, None, None, None, None, None, None, *dbs)
 
 
 class AttentionBlock:
@@ -508,9 +517,11 @@ class AttentionBlock:
         return dq, dk, dv
 
 
-def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0, pair_count=None):
+def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0, pair_count=None,
+                  bias_masters=()):
     p = float(dropout_p) if training else 0.0
-    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len, pair_count)
+    return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len, pair_count,
+                              *bias_masters)
 
 
 def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):
@@ -567,14 +578,16 @@ class EmbedSum(torch.autograd.Function):
     the type-0 row's gradient is the sum of the position rows' gradients (every token has exactly one position)."""
 
     @staticmethod
-    def forward(ctx, tok, pos_ids, word_w, pos_w, type_w, out_dtype):
+    def forward(ctx, tok, pos_ids, word_w, pos_w, type_w, out_dtype, bad_flag=None):
+        """``bad_flag``: optional int32[1] device tensor the kernel sets to 1 when an id lies outside its table (the ids are
+        then clamped, never read out of bounds); ``check_embed_ids`` is the raising, synchronising form."""
         _cuda(word_w, pos_w, type_w)
         tok, pos_ids = tok.long().contiguous(), pos_ids.long().contiguous()
         word, pos, typ = _f32c(word_w), _f32c(pos_w), _f32c(type_w)
         rows, p = tok.numel(), word.shape[1]
         out = torch.empty(rows, p, dtype=out_dtype, device=word.device)
         check(lib().gmlm_embed_sum_fwd(_ptr(word), _ptr(pos), _ptr(typ), _ptr(tok), _ptr(pos_ids), rows, p, word.shape[0],
-                                       pos.shape[0], _ptr(out), _dt(out), _stream()), "gmlm_embed_sum_fwd")
+                                       pos.shape[0], _ptr(out), _dt(out), _ptr(bad_flag), _stream()), "gmlm_embed_sum_fwd")
         ctx.save_for_backward(tok, pos_ids)
         ctx.cfg = (word.shape[0], pos.shape[0], type_w.shape[0], p)
         return out
@@ -586,18 +599,35 @@ class EmbedSum(torch.autograd.Function):
         vocab, npos, ntype, p = ctx.cfg
         g = g.contiguous()
         grads = []
+        # The segment sums feed fp32 master tables and a position row sums ~10^3 sequences: they are accumulated AND stored in
+        # fp32.  The aggregation kernel keeps one storage dtype for source and result, so a bf16 gradient is widened once
+        # ([T, P] fp32 transient: one pass, 1-2 % of the encoder backward) instead of rounding every sum to 8 bits.
+        g32 = g if g.dtype == torch.float32 else g.float()
         for ids, nseg in ((tok, vocab), (pos_ids, npos)):
             _, perm, rowptr, _ = _segment_sort(ids, None, None, 1, nseg)
-            acc = torch.empty(nseg, p, dtype=g.dtype, device=g.device)
-            _spmm(g, rowptr, perm, None, False, nseg, p, acc)
-            grads.append(acc.float())
+            acc = torch.empty(nseg, p, dtype=torch.float32, device=g.device)
+            _spmm(g32, rowptr, perm, None, False, nseg, p, acc)
+            grads.append(acc)
         d_type = torch.zeros(ntype, p, dtype=torch.float32, device=g.device)
         d_type[0] = grads[1].sum(0)
-        return None, None, grads[0], grads[1], d_type, None
+        return None, None, grads[0], grads[1], d_type, None, None
 
 
-def embed_sum(tok, pos_ids, word_w, pos_w, type_w, out_dtype):
-    return EmbedSum.apply(tok, pos_ids, word_w, pos_w, type_w, out_dtype)
+def embed_sum(tok, pos_ids, word_w, pos_w, type_w, out_dtype, bad_flag=None):
+    return EmbedSum.apply(tok, pos_ids, word_w, pos_w, type_w, out_dtype, bad_flag)
+
+
+def check_embed_ids(input_ids: torch.Tensor, lens: torch.Tensor, vocab: int, npos: int) -> None:
+    """What F.embedding / HF BERT enforce per call (an id outside the table raises), done ONCE for a static id tensor:
+    token ids in [0, vocab), sequence lengths <= max_position_embeddings.  One device sync; ``TokenizedTexts`` remembers
+    the tables it was checked against."""
+    if input_ids.numel() == 0:
+        return
+    lo, hi, lmax = int(input_ids.min()), int(input_ids.max()), int(lens.max()) if lens.numel() else 0
+    if lo < 0 or hi >= vocab:
+        raise IndexError(f"token id out of range: ids span [{lo}, {hi}], the word embedding table has {vocab} rows")
+    if lmax > npos:
+        raise IndexError(f"sequence of {lmax} tokens exceeds max_position_embeddings = {npos}")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -20,7 +20,8 @@ DEFAULT_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunable
 
 def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tuning_ms: int = 200,
                        rotating_buffer_mb: Optional[int] = None) -> bool:
-    """-> True when TunableOp is active with ``path`` (existing file, or tuning requested)."""
+    """-> True when TunableOp is active with ``path`` (a results file whose validators match this software stack, or
+    tuning requested); False = the library's default algorithms are in use."""
     path = path or DEFAULT_FILE
     if not tune and not os.path.exists(path):
         return False
@@ -33,7 +34,9 @@ def enable_gemm_tuning(path: Optional[str] = None, tune: bool = False, max_tunin
         if rotating_buffer_mb is not None:                          # operands rotate through a buffer larger than the caches: candidates are timed cold, as in a real step
             t.set_rotating_buffer_size(int(rotating_buffer_mb))
     else:
-        t.read_file(path)
+        if not t.read_file(path):                                   # validators (PyTorch / HIP / hipBLASLt / rocBLAS versions, GPU arch) rejected the file
+            disable_gemm_tuning()
+            return False
         # look-up only: whatever TunableOp may still want to write goes to a scratch file of this process, never to the
         # shipped picks (several ranks share them)
         import tempfile

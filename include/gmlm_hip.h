@@ -15,8 +15,9 @@
  *  - tensors are row-major and dense unless a stride argument says otherwise (strides in elements);
  *  - dtype: GMLM_F32 or GMLM_BF16 selects the storage type of activations; accumulation and all
  *    statistics are fp32; index arrays are int32 unless the reference hands over int64 (edge_index);
- *  - re-entrant: no mutable global state; safe to call twice with the same arguments
- *    (torch.utils.checkpoint recompute, main.py:278-314).
+ *  - re-entrant and thread-safe: the only state kept is a write-once "kernel attributes set on device d" bit per
+ *    kernel family, taken under a lock (one process may drive several GPUs / call from several host threads);
+ *    safe to call twice with the same arguments (torch.utils.checkpoint recompute, main.py:278-314).
  */
 #ifndef GMLM_HIP_H
 #define GMLM_HIP_H
@@ -214,9 +215,13 @@ int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* 
 
 /* BERT embedding sum (hf:modeling_bert.py:53-108 ahead of the LayerNorm): out[t] = word[tok[t]] + type0 + pos[pos_ids[t]],
  * fp32 tables, stored as `dtype` [rows, p]; replaces two gathers, two adds and a cast.  Its backward is a segment sum of the
- * output gradient by token id / position id (gmlm_segment_sort + gmlm_rgcn_mean_spmm with mean = 0). */
+ * output gradient by token id / position id (gmlm_segment_sort + gmlm_rgcn_mean_spmm with mean = 0).
+ * F.embedding raises on an id outside its table; here an id outside [0, vocab) / [0, npos) is never read out of bounds (it is
+ * clamped) and sets *bad_flag = 1 (device int32, nullable, NOT cleared by the call): the caller checks it when it next
+ * synchronises, or validates its (static) id tensors once up front, as the Python host does. */
 int gmlm_embed_sum_fwd(const float* word, const float* pos, const float* type0, const int64_t* tok, const int64_t* pos_ids,
-                       int64_t rows, int64_t p, int64_t vocab, int64_t npos, void* out, int dtype, gmlm_stream_t stream);
+                       int64_t rows, int64_t p, int64_t vocab, int64_t npos, void* out, int dtype, int32_t* bad_flag,
+                       gmlm_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8  attention-mask-weighted mean pooling + row scatter          (main.py:351-358)

@@ -140,6 +140,14 @@ def _harness_worker(rank, world, port, out_dir):
         for k, gr in ref_grads.items():
             gn = float(gr.norm())
             assert float((grads[k] - gr).norm()) <= 3e-4 * max(gn, 1e-3), (rank, k)
+        # steps 2-4 run with the LEARNED bucket set: rank 0's PLM / head buckets become final (and launch) ahead of the GNN
+        # backward's collectives, rank 1 (no active node, no PLM gradient) launches them in finish() - the order mismatch
+        # that needs the buckets' own communicator; the trajectories must stay on the single-GPU ones
+        for it in range(3):
+            ra = harness.train_step(ref, ref_opt, None, x.to(dev), ei.to(dev), tok, y.to(dev), mask.to(dev), autocast=False)
+            rb = harness.train_step(model, opt, None, x[lo:hi].to(dev), ei.to(dev), tok_l, y[lo:hi].to(dev), mask[lo:hi].to(dev),
+                                    autocast=False)
+            assert not rb.skipped and abs(rb.loss - ra.loss) < 5e-5 * max(1.0, abs(ra.loss)), (it, rb, ra)
         # no active node anywhere: every rank skips (and none is left waiting in a collective)
         none = torch.zeros(hi - lo, dtype=torch.bool, device=dev)
         assert harness.train_step(model, opt, None, x[lo:hi].to(dev), ei.to(dev), tok_l, y[lo:hi].to(dev), none, autocast=False).skipped
@@ -149,6 +157,12 @@ def _harness_worker(rank, world, port, out_dir):
         lp_ref = harness.pretrain_step(ref, ref_opt, x.to(dev), ei.to(dev), m1.to(dev), m2.to(dev), autocast=False)
         lp = harness.pretrain_step(model, opt, x[lo:hi].to(dev), ei.to(dev), m1[lo:hi].to(dev), m2[lo:hi].to(dev), autocast=False)
         assert abs(lp - lp_ref) < 5e-4 * max(1.0, abs(lp_ref)), (lp, lp_ref)
+        # the pre-training step produces no PLM / head / cross-attention gradient on any rank: those parameters are in the
+        # learned bucket set (train_step ran first) and must still end with grad None, like the single-GPU step, so that
+        # AdamW does not decay them or move their moments
+        none_ref = {k for k, p in ref.named_parameters() if p.grad is None}
+        none_got = {k for k, p in model.named_parameters() if p.grad is None}
+        assert none_got == none_ref and any(k.startswith("plm_encoder.") for k in none_got), none_got ^ none_ref
         open(os.path.join(out_dir, f"hok{rank}"), "w").write("ok")
     finally:
         dist.destroy_process_group()

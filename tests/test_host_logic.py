@@ -48,3 +48,41 @@ def test_npz_reader_layout_and_split(tmp_path):
         load_npz_dataset(str(obj))
     data3, _, _ = load_npz_dataset(str(obj), allow_pickle=True)
     assert data3.node_texts == data2.node_texts and data3.label_texts == ["a", "b", "c"]
+
+
+def test_tokenize_cache_is_constant_time_per_step_and_notices_changes():
+    """GraphTextLM.tokenize (host side of main.py:342-345): the same text list costs no tokeniser call and no O(N) pass on
+    later steps; a list that grew, shrank or was rewritten is tokenised again."""
+    from transformers import BertConfig, BertModel
+    import gmlm_amd
+
+    calls = []
+
+    class Tok:
+        def __call__(self, texts, **kw):
+            calls.append(len(texts))
+            l = max(len(s.split()) for s in texts)
+            ids = torch.zeros(len(texts), l, dtype=torch.long)
+            am = torch.zeros_like(ids)
+            for i, s in enumerate(texts):
+                k = len(s.split())
+                ids[i, :k] = torch.arange(1, k + 1)
+                am[i, :k] = 1
+            return {"input_ids": ids, "attention_mask": am}
+
+    enc = BertModel(BertConfig(vocab_size=50, hidden_size=64, num_hidden_layers=1, num_attention_heads=1,
+                               intermediate_size=64, max_position_embeddings=32))
+    m = gmlm_amd.GraphTextLM(8, 4, 3, plm_encoder=enc, plm_tokenizer=Tok())
+    texts = [f"node {i} has text" for i in range(1000)]
+    t1 = m.tokenize(texts)
+    assert calls == [1000] and tuple(t1.lens_host[:3].tolist()) == (4, 4, 4)
+    assert m.tokenize(texts) is t1 and m.tokenize(texts) is t1 and calls == [1000]
+    assert m.tokenize(t1) is t1                                           # pre-tokenised input passes through
+    texts.append("one more")
+    t2 = m.tokenize(texts)
+    assert t2 is not t1 and calls == [1000, 1001]
+    texts[:] = [s + " changed" for s in texts]                            # rewritten in place, same length
+    t3 = m.tokenize(texts)
+    assert t3 is not t2 and calls[-1] == 1001 and int(t3.lens_host[0]) == 5
+    m.clear_caches()
+    assert m.tokenize(texts) is not t3
