@@ -95,3 +95,25 @@ def oracle_model_from_config(cfg):
     m = OracleGraphTextLM(cfg["f_in"], cfg["hc"], cfg["c"], plm_sd, plm["heads"])
     m.load_reference_state(sd)
     return m, sd
+
+
+def attn_dropout_scale(seed: int, slab: int, nq: int, nk: int, p: float, device="cpu"):
+    """The attention kernels' replayable probability-dropout mask, restated with torch integer arithmetic (checker only;
+    DESIGN.md section 4 'Dropout'): one 32-bit hash word per 2 x 2 (query, key) tile,
+    word = lowbias32(base + (q >> 1) * C1 + (k >> 1) * C2), base = (lo32(seed) ^ hi32(seed)) + slab * C3, the element's 8-bit
+    field = bits [16 (q & 1) + 8 (k & 1), +8), kept when field >= round(256 p); kept elements are scaled by 256 / (256 - th).
+    ``slab`` = (batch * heads + head) * lq for padded tensors.  Returns the [nq, nk] float64 multiplier (0 or keep scale)."""
+    m32 = 0xFFFFFFFF
+    c1, c2, c3 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D
+    th = int(round(p * 256.0))
+    th = max(0, min(255, th))
+    ks = 256.0 / (256.0 - th)
+    base = (((seed & m32) ^ ((seed >> 32) & m32)) + (slab * c3)) & m32
+    q = torch.arange(nq, dtype=torch.int64, device=device)[:, None]
+    k = torch.arange(nk, dtype=torch.int64, device=device)[None, :]
+    u = (base + (q >> 1) * c1 + (k >> 1) * c2) & m32
+    u = u ^ (u >> 16)
+    u = (u * 0x7FEB352D) & m32
+    u = u ^ (u >> 15)
+    field = (u >> (16 * (q & 1) + 8 * (k & 1))) & 0xFF
+    return (field >= th).to(torch.float64) * ks

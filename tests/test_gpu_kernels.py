@@ -405,17 +405,18 @@ def test_spmm_power_law_long_segments(dev):
     assert torch.equal(h, RGCNAggregate.apply(xg, csr))          # deterministic
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 5e-2)])
-def test_attention_online_softmax_rescale_branch(dev, dt, tol):
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_online_softmax_rescale_branch(dev, dt):
     """The kernel skips the running-max rescale while the max grows by < 2^6 and rescales otherwise.  Random
     data almost never takes the rescale branch after the first tile, so force it: a few keys far down the
     sequence score 40+ above everything before them for some queries (and not for others).
 
-    bf16 tolerance 5e-2: the forced scores reach 50-100 (natural units).  The pipelined forward pre-multiplies q by
-    scale * log2(e) and rounds once more to bf16 (relative 2^-9 per element), i.e. a score error of about
-    |s| * 2^-9 / sqrt(d) * sqrt(d) ~ 0.1-0.2 at |s| = 100 in the worst element -> a few % on a probability that is
-    not saturated.  (The reference's own GPU arithmetic is fp16 autocast, main.py:543: its scores carry an absolute
-    error of 2^-4 at that magnitude.)  At |s| <~ 15 - trained attention logits - the effect is < 0.5 %."""
+    fp32: against the fp32 torch reference at 2e-5.  bf16: the forced scores reach 50-100 (natural units) and the pipelined
+    forward rounds q * scale * log2(e) once more to bf16, i.e. a score error of ~|s| 2^-9 ~ 0.1-0.2 in the worst element:
+    against plain fp32 that is a few % on a probability that is not saturated (bar 5e-2: precision, not the kernel).  The
+    real check is therefore against the oracle's bf16-emulating attention (oracle/bf16_emulation.py: same pre-scaling, same
+    reference-max schedule per 32-query wave and 32-key block, same split lse / delta terms in the backward): forward AND
+    all three gradients within 5e-2 relative, elementwise."""
     from gmlm_amd.ops import attention
     b, h, l, d = 1, 2, 400, 64
     g = torch.Generator().manual_seed(17)
@@ -424,17 +425,33 @@ def test_attention_online_softmax_rescale_branch(dev, dt, tol):
     k[0, 333] = q[0, 200] * 9.0       # tile 5: another jump for query 200
     k[0, 399] = q[0, 5] * 12.0        # last (partial) tile: second jump for query 5
     q, k, v = q.to(dt), k.to(dt), v.to(dt)
-    ref = _attn_ref(q.float(), k.float(), v.float(), None, h, d ** -0.5)
+    go = torch.randn(b, l, h * d, generator=g).to(dt)
     qd, kd, vd = (x.to(dev).requires_grad_(True) for x in (q, k, v))
     y = attention(qd, kd, vd, None, h, d ** -0.5)
-    np.testing.assert_allclose(y.float().detach().cpu().numpy(), ref.numpy(), rtol=tol, atol=tol)
-    go = torch.randn(b, l, h * d, generator=g)
+    y.backward(go.to(dev))
     qr, kr, vr = (x.float().clone().requires_grad_(True) for x in (q, k, v))
-    _attn_ref(qr, kr, vr, None, h, d ** -0.5).backward(go)
-    y.backward(go.to(dev, dt))
-    for a, r_ in ((qd, qr), (kd, kr), (vd, vr)):
-        sc = float(r_.grad.abs().max())
-        np.testing.assert_allclose(a.grad.float().cpu().numpy(), r_.grad.numpy(), rtol=50 * tol, atol=2 * tol * sc)
+    ref = _attn_ref(qr, kr, vr, None, h, d ** -0.5)
+    ref.backward(go.float())
+    if dt == torch.float32:
+        np.testing.assert_allclose(y.detach().cpu().numpy(), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+        for a, r_ in ((qd, qr), (kd, kr), (vd, vr)):
+            sc = float(r_.grad.abs().max())
+            np.testing.assert_allclose(a.grad.cpu().numpy(), r_.grad.numpy(), rtol=1e-3, atol=4e-5 * sc)
+        return
+    np.testing.assert_allclose(y.float().detach().cpu().numpy(), ref.detach().numpy(), rtol=5e-2, atol=5e-2)
+    import bf16_emulation as E
+    heads = lambda t_: t_[0].float().view(l, h, d).transpose(0, 1).contiguous()                  # [h, L, d]
+    qe, ke, ve = (heads(x).requires_grad_(True) for x in (q, k, v))
+    ye = E._LongAttention.apply(qe, ke, ve, d ** -0.5)
+    ye.backward(heads(go))
+    back = lambda t_: t_.transpose(0, 1).reshape(1, l, h * d)
+    for name, a, r_ in (("out", y.detach(), back(ye.detach())), ("dq", qd.grad, back(qe.grad)), ("dk", kd.grad, back(ke.grad)),
+                        ("dv", vd.grad, back(ve.grad))):
+        a = a.float().cpu()
+        sc = float(r_.abs().max())
+        bad = ((a - r_).abs() > 5e-2 * r_.abs() + 4e-3 * sc)                # one bf16 ulp of the largest element absolute
+        print(f"  rescale branch bf16 {name}: max|err|/max = {float((a - r_).abs().max()) / sc:.2e}, elements off = {int(bad.sum())}")
+        assert int(bad.sum()) == 0, name
 
 
 @pytest.mark.parametrize("ra,nb,cols", [(1, 30, 768 * 1536), (4, 30, 64 * 128), (5, 32, 1000), (3, 7, 2096 * 16)])

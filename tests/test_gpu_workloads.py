@@ -82,39 +82,53 @@ def test_squirrel_h768_bert_base_fp32_vs_oracle_and_bf16_budget(dev):
     g32 = {k: p.grad.detach().double().cpu() for k, p in m32.named_parameters() if p.grad is not None}
     del m32
     torch.cuda.empty_cache()
-    # bf16 (the dtype bench.py reports) against the fp32 HIP path on the same inputs.  Budget: every GEMM / attention
-    # operand is rounded to 8 mantissa bits (relative 2^-9), accumulation and normalisation statistics stay fp32; through
-    # 4 RGCN + 12 BERT + 2 cross-attention + 3 head layers the roundings add like a random walk: ~2^-9 * sqrt(21 layers
-    # * ~3 roundings) * |activation scale ~2| ~ 3e-2 on logits of O(1).
+    # bf16 (the dtype bench.py reports).  The budget against fp32 is what 8-bit mantissas cost through 4 RGCN + 12 BERT +
+    # 2 cross-attention + 3 head layers (kept as a printed figure and a loose sanity bound); the CHECK is against the
+    # oracle's bf16-emulating mode (oracle/bf16_emulation.py), which rounds where the kernels round: there the two must agree
+    # far more tightly than either agrees with fp32, on the logits and on EVERY gradient tensor - including the query / key
+    # projections of the deep encoder layers, whose fp32-vs-bf16 cosine is poor (0.38 at layer 11's key weight) because
+    # their gradient is what is left after the rows of dS cancel: if that deviation is reduced precision, the emulation
+    # reproduces it; if a kernel were off, it would not.
     mbf, lbf, lossbf = run(torch.bfloat16)
     d = (lbf - l32).abs()
     print(f"\nsquirrel h768: fp32 vs oracle max|dlogit| = {err:.2e} (worst grad-norm rel err {worst[0]:.2e} at {worst[1]}); "
           f"bf16 vs fp32: max {float(d.max()):.3e} mean {float(d.mean()):.3e} dloss {abs(lossbf - loss32):.3e}")
     assert float(d.max()) <= 3e-2 and float(d.mean()) <= 6e-3 and abs(lossbf - loss32) <= 5e-3   # measured: 1.05e-2 / 2.5e-3 / 9e-4
-    # gradients: direction (cosine) and size against the fp32 path, per parameter tensor.  Tensors whose fp32 gradient
-    # is tiny against the model's gradient scale (the query / key projections of a random-init encoder: the softmax is
-    # nearly flat, dS ~ 0) are rounding-dominated in ANY reduced precision; they are held to an absolute error of 1 % of
-    # the largest per-tensor gradient norm instead of a relative one.
+    import bf16_emulation as E
+    om.zero_grad(set_to_none=True)
+    le = E.forward(om, data["x"], data["edge_index"], ids, am, mask)
+    loss_e = F.cross_entropy(le[mask], data["y"][mask], label_smoothing=0.2)
+    loss_e.backward()
+    de = (lbf - le.detach()).abs()
+    print(f"bf16 HIP vs bf16-emulating oracle: logits max {float(de.max()):.3e} mean {float(de.mean()):.3e} dloss {abs(lossbf - float(loss_e)):.3e} "
+          f"(emulation vs fp32 oracle: max {float((le.detach() - ref.detach()).abs().max()):.3e})")
+    assert float(de.max()) <= 4e-3 and float(de.mean()) <= 6e-4 and abs(lossbf - float(loss_e)) <= 5e-4
     rows = []
+    ge = {k: p.grad for k, p in om.named_parameters()}
     for k, p in mbf.named_parameters():
-        if p.grad is None or k not in g32:
+        ok = "plm_params." + k[len("plm_encoder."):].replace(".", "/") if k.startswith("plm_encoder.") else k
+        b_ = ge.get(ok)
+        if p.grad is None or b_ is None:
+            assert (p.grad is None or float(p.grad.abs().max()) == 0) and (b_ is None or float(b_.abs().max()) == 0), k
             continue
-        a, b = p.grad.detach().double().cpu().reshape(-1), g32[k].reshape(-1)
-        rows.append((k, float(b.norm()), float(a.norm()), float(torch.dot(a, b) / (a.norm() * b.norm()).clamp(min=1e-30)), float((a - b).norm())))
-    gmax = max(r[1] for r in rows)
-    big = [r for r in rows if r[1] >= 1e-2 * gmax]
-    small = [r for r in rows if r[1] < 1e-2 * gmax]
-    worst_cos = min(big, key=lambda r: r[3])
-    worst_ratio = max(big, key=lambda r: abs(r[2] / r[1] - 1))
-    worst_abs = max(small, key=lambda r: r[4]) if small else None
-    print(f"bf16 gradients vs fp32 ({len(big)} tensors with norm >= 1% of the largest, {gmax:.3e}): min cosine {worst_cos[3]:.4f} at {worst_cos[0]}, "
-          f"worst |norm ratio - 1| {abs(worst_ratio[2] / worst_ratio[1] - 1):.3f} at {worst_ratio[0]}; "
-          + (f"{len(small)} small tensors: worst |diff| {worst_abs[4]:.2e} = {worst_abs[4] / gmax:.2e} of the largest norm at {worst_abs[0]}" if small else ""))
-    for r in sorted(rows, key=lambda r: r[3])[:6]:
-        print(f"    {r[0]:60s} |g32| {r[1]:.3e} |gbf| {r[2]:.3e} cos {r[3]:.4f} |diff| {r[4]:.2e}")
-    assert worst_cos[3] >= 0.999, worst_cos                                   # measured: 0.9999
-    assert abs(worst_ratio[2] / worst_ratio[1] - 1) <= 0.03, worst_ratio      # measured: 0.011
-    assert worst_abs is None or worst_abs[4] <= 2e-3 * gmax, worst_abs        # measured: 1.6e-4
+        a, b_ = p.grad.detach().double().cpu().reshape(-1), b_.double().reshape(-1)
+        a32 = g32[k].reshape(-1)
+        rows.append((k, float(b_.norm()), float(a.norm()), float(torch.dot(a, b_) / (a.norm() * b_.norm()).clamp(min=1e-30)),
+                     float(torch.dot(a, a32) / (a.norm() * a32.norm()).clamp(min=1e-30))))
+    gmax = max(r_[1] for r_ in rows)
+    # attention key biases: the softmax does not see a shift of all scores of a query, their gradient is analytically zero;
+    # both sides must say so (no direction to compare)
+    zero = [r_ for r_ in rows if r_[0].endswith("key.bias") or r_[0].endswith("k_proj.bias")]
+    for r_ in zero:
+        assert r_[1] <= 1e-6 * gmax and r_[2] <= 1e-4 * gmax, r_
+    live = [r_ for r_ in rows if r_ not in zero]
+    print(f"bf16 gradients, {len(live)} tensors (largest norm {gmax:.3e}): lowest cosines against the emulation | against fp32")
+    for r_ in sorted(live, key=lambda r_: r_[3])[:8]:
+        print(f"    {r_[0]:62s} |g_emul| {r_[1]:.3e} |g_hip| {r_[2]:.3e} cos(emul) {r_[3]:.5f} cos(fp32) {r_[4]:.4f}")
+    worst_cos = min(live, key=lambda r_: r_[3])
+    worst_ratio = max(live, key=lambda r_: abs(r_[2] / r_[1] - 1))
+    assert worst_cos[3] >= 0.99, worst_cos                                    # EVERY tensor, no norm exemption
+    assert abs(worst_ratio[2] / worst_ratio[1] - 1) <= 0.03, worst_ratio
 
 
 def _chung_lu(n, e, seed):
