@@ -46,10 +46,10 @@ SIGNATURES = {
     "gmlm_bias_res_layernorm_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i32, _f32, _u64, _p, _p, _p, _p, _p,
                                               _p, _i32, _p, _sz, _p]),
     "gmlm_attention_fwd": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _u64, _p,
-                                     _p, _p, _i32, _p, _i64, _p]),
+                                     _p, _p, _p, _i32, _p, _i64, _p, _i64, _p]),
     "gmlm_attention_bwd_workspace_bytes": (_sz, [_i64, _i64, _i64, _i64, _i64]),
     "gmlm_attention_bwd": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32,
-                                     _f32, _u64, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p, _sz, _p, _p, _p]),
+                                     _f32, _u64, _p, _p, _p, _p, _i64, _i64, _i64, _i32, _p, _i64, _p, _sz, _p, _p, _p, _p, _i64, _p]),
     "gmlm_embed_sum_fwd": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i64, _i64, _p, _i32, _p, _p]),
     "gmlm_meanpool_scatter_fwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i32, _p, _p]),
     "gmlm_meanpool_scatter_bwd": (C.c_int, [_p, _p, _p, _i64, _i64, _i64, _p, _i32, _p, _p]),

@@ -194,7 +194,7 @@ def _mm(x, wc, bc, masters, residual=False, bias_grad=True):
         return _Linear.apply(x, wc, bc, residual, bias_grad, *masters)
 
 
-def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None):
+def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None, groups=None):
     pdim = h.shape[-1]
     d = pdim // heads
     scale = d ** -0.5
@@ -204,7 +204,7 @@ def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len
         # bias master -> attention op, no side channel between the two backward functions
         qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv[:3], residual=True, bias_grad=False)   # [B, L, 3P] or packed [T, 3P]
         ctx = ops.attention_qkv(qkv, None if cu is not None else lens, heads, scale, p_attn, training, cu, max_len, pair_count,
-                                bias_masters=lw.m_qkv[3:])
+                                bias_masters=lw.m_qkv[3:], groups=groups)
     else:
         qkv, h_res = _mm(h, lw.wqkv, lw.bqkv, lw.m_qkv, residual=True)
         ctx = attention_any_dim(qkv[..., :pdim], qkv[..., pdim:2 * pdim], qkv[..., 2 * pdim:], lens, heads, scale, p_attn,
@@ -245,11 +245,12 @@ def bert_encode(plm, input_ids: torch.Tensor, lens: torch.Tensor, cd: torch.dtyp
 
 def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_seqlens: torch.Tensor, max_len: int,
                        cd: torch.dtype, training: bool = False, gradient_checkpointing: bool = False, weights=None,
-                       pair_count=None):
+                       pair_count=None, groups=None):
     """Variable-length (packed) encoder pass: ``token_ids`` int [T] = the valid tokens of all sequences back to
     back, ``pos_ids`` int [T] = position of each token inside its sequence, ``cu_seqlens`` int32 [B+1].
     Returns [T, P].  Every GEMM / LayerNorm / GELU row is a real token and attention never sees padding
-    (same result per token as the padded form: padded keys have probability exactly 0 there)."""
+    (same result per token as the padded form: padded keys have probability exactly 0 there).
+    ``groups``: optional ``ops.pack_sequence_groups`` boundaries (device int32) for the short-sequence attention kernels."""
     cfg = plm.config
     emb = plm.embeddings
     # word + type-0 + position rows in one pass (fp32 sums in torch's order, stored as cd); backward = segment sums by id
@@ -265,10 +266,10 @@ def bert_encode_packed(plm, token_ids: torch.Tensor, pos_ids: torch.Tensor, cu_s
         weights = prepare_weights(plm, cd)
     for lw in weights:
         if gradient_checkpointing and training and torch.is_grad_enabled():
-            h = checkpoint(_layer, lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count,
+            h = checkpoint(_layer, lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count, groups,
                            use_reentrant=False)
         else:
-            h = _layer(lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count)
+            h = _layer(lw, h, None, heads, training, p_hidden, p_attn, eps, cu_seqlens, max_len, pair_count, groups)
     return h
 
 

@@ -12,6 +12,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 struct AttnParams {
   const void *q, *k, *v, *out, *dout;
+  const void* out_lo;         // backward, bf16: optional residual of the forward output, O = out + out_lo to 2^-17 (delta = rowsum(dO * O) then
+                              // has fp32-like accuracy instead of carrying the 2^-9 rounding of the stored output); NULL = out alone
+  void* o_lo_w;               // forward, bf16: where to store that residual (NULL = not wanted)
+  const int32_t* groups;      // short-sequence kernels, packed mode: sequences [groups[g], groups[g+1]) form work item g (NULL: one sequence each)
   const float* lse;
   const int32_t* kv_len;
   const int32_t* cu;      // varlen (packed) mode: sequence b owns rows [cu[b], cu[b+1]) of q AND k/v; lq = total rows
@@ -217,6 +221,24 @@ __device__ __forceinline__ void store_t(T* rowptr /* + db*32 applied */, const f
       w.y = (uint32_t)f32_to_bf16(acc[4 * g4 + 2] * mul) | ((uint32_t)f32_to_bf16(acc[4 * g4 + 3] * mul) << 16);
       *reinterpret_cast<uint2*>(p) = w;
     }
+  }
+}
+
+// bf16 residual of the same store: lo = bf16(x - bf16(x)), x = acc * mul, so that hi + lo carries x to 2^-17 (the backward's
+// delta = rowsum(dO * O) is then as accurate as with an fp32 output)
+__device__ __forceinline__ void store_t_lo(bf16_t* rowptr, const f32x16& acc, float mul, int h) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    uint32_t lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float x = acc[4 * g4 + j] * mul;
+      lo[j] = (uint32_t)f32_to_bf16(x - bf16_to_f32(f32_to_bf16(x)));
+    }
+    uint2 w;
+    w.x = lo[0] | (lo[1] << 16);
+    w.y = lo[2] | (lo[3] << 16);
+    *reinterpret_cast<uint2*>(rowptr + 8 * g4 + 4 * h) = w;
   }
 }
 

@@ -457,6 +457,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
+    if (p.o_lo_w) {
+      T* olg = static_cast<T*>(p.o_lo_w) + ((qbase + q_row) * p.h + hd) * D;
+#pragma unroll
+      for (int d = 0; d < DB; ++d) store_t_lo(olg + d * 32, o[d], inv, h);
+    }
     if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
   }
 #ifdef GMLM_ATTN_STAMP

@@ -161,16 +161,23 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(AttnParams p) {
     T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
+    if constexpr (sizeof(T) == 2) {
+      if (p.o_lo_w) {
+        T* olg = static_cast<T*>(p.o_lo_w) + ((qbase + q_row) * p.h + hd) * D;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) store_t_lo(olg + d * 32, o[d], inv, h);
+      }
+    }
     if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward: delta[b,h,q] = sum_d dO * O
+// backward: delta[b,h,q] = sum_d dO * O   (O = o + o_lo when the forward stored the bf16 residual of its output)
 // ------------------------------------------------------------------------------------------------
 // a group of d/V lanes owns one (b, q, h) row: the wave reads 64 x 16 contiguous bytes per instruction
 template <typename T>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ dout,
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ o_lo, const T* __restrict__ dout,
                                                           int64_t rows /* b*lq*h */, int d, int64_t lq, int64_t hn,
                                                           float* __restrict__ delta) {
   constexpr int V = Store<T>::kVec;
@@ -183,6 +190,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
     float a[V], g[V];
     Store<T>::ldv(o + row * d + c * V, a);
     Store<T>::ldv(dout + row * d + c * V, g);
+    if (o_lo) {
+      float al[V];
+      Store<T>::ldv(o_lo + row * d + c * V, al);
+#pragma unroll
+      for (int v = 0; v < V; ++v) a[v] += al[v];
+    }
 #pragma unroll
     for (int v = 0; v < V; ++v) acc += a[v] * g[v];
   }
@@ -534,341 +547,6 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(AttnParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// backward, sequences of <= 128 tokens (bf16): ONE launch per (sequence, head), all of Q, K, V, dO resident in LDS.
-// Every thread issues its 16-byte pieces of the five tensors (Q, K, V, dO, O) up front with the coalesced pattern
-// (8 lanes per 128-byte row): one memory round trip, 20 loads in flight per thread.  delta = rowsum(dO * O) is
-// formed from the staging registers (O never reaches LDS).  After ONE barrier the image is read-only: phase 1 is
-// the dQ kernel's body (query on the lane), phase 2 the dK/dV kernel's body (key on the lane); the per-lane operand
-// fragments of both come from LDS (ds_read_b128), not from global memory - the earlier form loaded them per lane
-// from global (32 different 128-byte lines per wave-instruction, each line touched by 4 instructions): 6x the
-// necessary L1 accesses and the vector L1 stalled on pending lines half of the time (TCP_PENDING_STALL_CYCLES).
-// The reference tokenises to max_length = 128 (main.py:340): this is the text encoder's attention backward.
-// R = row capacity of the workgroup (32, 64, 96 or 128) = 32 x its wave count; LDS is proportional to R.  Padded
-// batches get the smallest capacity that fits; packed batches use max_len's class for all sequences (per-class
-// launches were measured and do not pay).
-// ------------------------------------------------------------------------------------------------
-template <int D, bool DROP, int R>
-__global__ __launch_bounds__(2 * R) void attn_bwd_short_kernel(AttnParams p) {
-  using T = bf16_t;
-  constexpr int NT = 2 * R, PITCH = D + Pad<T>::v, DB = D / 32, CPR = D / 8, PER = R * CPR / NT;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tk = reinterpret_cast<T*>(smem_raw);
-  T* tv = tk + R * PITCH;
-  T* tq = tv + R * PITCH;
-  T* tdo = tq + R * PITCH;
-  float* lse_s = reinterpret_cast<float*>(tdo + R * PITCH);
-  float* dl_s = lse_s + R;
-  // bias-gradient coefficients (p.dbias_part): per key c_k = sum_q dS[q,k], per query pm_q = sum_k P'[q,k] (bf16): [2][R]
-  T* coef = reinterpret_cast<T*>(dl_s + R);
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int64_t b = blockIdx.x / p.h, hd = blockIdx.x % p.h;
-  const bool bgrad = p.dbias_part != nullptr;                // block-uniform
-  if (bgrad)
-    for (int i = tid; i < 2 * R; i += NT) coef[i] = f32_to_bf16(0.f);     // waves that skip a phase leave zeros
-  int64_t lq_, lk_, qbase, kbase, lse_base;
-  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
-  int64_t kvlen = lk_;
-  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
-  const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
-  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
-  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
-  const T* dog = static_cast<const T*>(p.dout) + (qbase * p.h + hd) * D;
-  const T* og = static_cast<const T*>(p.out) + (qbase * p.h + hd) * D;
-  const int do_stride = (int)(p.h * D);
-  const int lq = (int)lq_, lk = (int)lk_, kvl = (int)kvlen;  // <= 128: 32-bit index arithmetic below
-  // ---- staging: all loads first (32-bit offsets: rows <= 128, strides < 2^24), then delta, then the LDS image ----
-  uint4 rk[PER], rv[PER], rq[PER], rdo[PER], ro[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
-    rk[k] = rv[k] = rq[k] = rdo[k] = ro[k] = make_uint4(0, 0, 0, 0);
-    if (row < lk) {
-      rk[k] = *reinterpret_cast<const uint4*>(kg + (uint32_t)(row * (int)p.k_stride + col));
-      rv[k] = *reinterpret_cast<const uint4*>(vg + (uint32_t)(row * (int)p.v_stride + col));
-    }
-    if (row < lq) {
-      rq[k] = *reinterpret_cast<const uint4*>(qg + (uint32_t)(row * (int)p.q_stride + col));
-      rdo[k] = *reinterpret_cast<const uint4*>(dog + (uint32_t)(row * do_stride + col));
-      ro[k] = *reinterpret_cast<const uint4*>(og + (uint32_t)(row * do_stride + col));
-    }
-  }
-  if (tid < R) lse_s[tid] = tid < lq ? p.lse[lse_base + tid] * kLog2e : INFINITY;   // +inf: a row past the sequence gets probability 0
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
-    float a[8], g[8];
-    Store<T>::unpack(ro[k], a);
-    Store<T>::unpack(rdo[k], g);
-    float d = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) d = fmaf(a[e], g[e], d);
-    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);   // the CPR = 8 lanes of the row
-    if ((i % CPR) == 0) dl_s[row] = d;                    // rows past the sequence: 0
-    *reinterpret_cast<uint4*>(tk + row * PITCH + col) = rk[k];
-    *reinterpret_cast<uint4*>(tv + row * PITCH + col) = rv[k];
-    *reinterpret_cast<uint4*>(tq + row * PITCH + col) = rq[k];
-    *reinterpret_cast<uint4*>(tdo + row * PITCH + col) = rdo[k];
-  }
-  __syncthreads();
-  const float sl2 = p.scale * kLog2e;
-  const uint32_t d_base = drop_base(attn_seed(p), lse_base);
-  auto frag = [&](const T* tile, int row, RowFrag<T, D>& f) {          // MFMA B-operand fragment of a staged row
-#pragma unroll
-    for (int s = 0; s < D / 16; ++s) f.v[s] = *reinterpret_cast<const bf16x8*>(tile + row * PITCH + 16 * s + 8 * h);
-  };
-  // ---- phase 1: dQ (query on the lane; K, V as MFMA A operands) ----------------------------------------
-  if (w * 32 < lq) {
-    const int q_row = w * 32 + r;
-    RowFrag<T, D> qf, dof;
-    frag(tq, q_row, qf);
-    frag(tdo, q_row, dof);
-    const float lse2 = lse_s[q_row], dl = dl_s[q_row];
-    const uint32_t dq_u = d_base + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
-    const int q_odd = q_row & 1;
-    f32x16 dq[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) dq[d][i] = 0.f;
-    // scores of one 32-key block -> dS^T; MASKED only for the block that straddles kv_len (block-uniform choice:
-    // full blocks carry no per-key compare / select at all)
-    float pm = 0.f;                                         // this half-wave's share of sum_k P'[q,k] (dropped probabilities)
-    auto block_ds = [&](auto masked_c, int kb, f32x16& s, const f32x16& dp) {
-      constexpr bool MASKED = decltype(masked_c)::value;
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
-        float a0 = fmaf(s[i], sl2, -lse2), a1 = fmaf(s[i + 1], sl2, -lse2);
-        if (MASKED) {
-          const int key = kb * 32 + acc_row(i, h);          // even; registers i, i+1 = keys key, key+1
-          a0 = key < kvl ? a0 : -INFINITY;                  // probability exactly 0 through the exponent, no branch
-          a1 = key + 1 < kvl ? a1 : -INFINITY;
-        }
-        const float p0 = fast_exp2(a0), p1 = fast_exp2(a1);
-        float m0 = 1.f, m1 = 1.f;
-        if (DROP) drop_pair_q(dq_u + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
-        s[i] = p0 * (dp[i] * m0 - dl);
-        s[i + 1] = p1 * (dp[i + 1] * m1 - dl);
-        if (bgrad) pm = fmaf(p1, m1, fmaf(p0, m0, pm));
-      }
-    };
-#pragma unroll
-    for (int kb = 0; kb < R / 32; ++kb) {
-      if (kb * 32 >= kvl) break;                          // block-uniform
-      f32x16 s, dp;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-      mma_rows<D>(tk, PITCH, kb * 32, qf, s, r, h);
-      mma_rows<D>(tv, PITCH, kb * 32, dof, dp, r, h);
-      if ((kb + 1) * 32 <= kvl) block_ds(std::false_type{}, kb, s, dp);
-      else block_ds(std::true_type{}, kb, s, dp);
-      mma_acc<D>(tk, PITCH, kb * 32, s, dq, lane);
-    }
-    if (q_row < lq) {
-      T* dqg = static_cast<T*>(p.dq) + (qbase + q_row) * p.dq_stride + hd * D;
-#pragma unroll
-      for (int d = 0; d < DB; ++d) store_t<T>(dqg + d * 32, dq[d], p.scale, h);
-    }
-    if (bgrad) {
-      pm = xhalf_sum(pm);
-      if (h == 0) coef[R + q_row] = f32_to_bf16(pm);
-    }
-  }
-  // ---- phase 2: dK, dV (key on the lane; Q, dO as MFMA A operands) -------------------------------------
-  if (w * 32 < lk) {
-    const int key = w * 32 + r;
-    const bool live = w * 32 < kvl;                         // block-uniform: else dK = dV = 0 for the whole wave
-    f32x16 dk[DB], dv[DB];
-#pragma unroll
-    for (int d = 0; d < DB; ++d)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { dk[d][i] = 0.f; dv[d][i] = 0.f; }
-    if (live) {
-      RowFrag<T, D> kf, vf;
-      frag(tk, key, kf);
-      frag(tv, key, vf);
-      const uint32_t dk_u = d_base + (uint32_t)(key >> 1) * kDropC2 + (uint32_t)(2 * h) * kDropC1;
-      const int k_odd = key & 1;
-      const float kmask = key < kvl ? 0.f : INFINITY;       // subtracted from the exponent: a masked key's probabilities are exactly 0
-      float ck = 0.f;                                       // this half-wave's share of sum_q dS[q,key]
-#pragma unroll
-      for (int qb = 0; qb < R / 32; ++qb) {
-        if (qb * 32 >= lq) break;                           // block-uniform
-        f32x16 s, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-        mma_rows<D>(tq, PITCH, qb * 32, kf, s, r, h);
-        mma_rows<D>(tdo, PITCH, qb * 32, vf, dp, r, h);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int q4 = qb * 32 + 8 * g4 + 4 * h;           // accumulator registers 4*g4 .. 4*g4+3 = queries q4 .. q4+3
-          const float4 l4 = *reinterpret_cast<const float4*>(lse_s + q4);
-          const float4 d4 = *reinterpret_cast<const float4*>(dl_s + q4);
-          const float lq4[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-          for (int j = 0; j < 4; j += 2) {
-            const int i = 4 * g4 + j;                        // registers i, i+1 = queries q4 + j, + 1 (even, odd)
-            // rows past the sequence carry lse = +inf in LDS (exponent -inf -> probability 0)
-            const float p0 = fast_exp2(fmaf(s[i], sl2, -lq4[j]) - kmask), p1 = fast_exp2(fmaf(s[i + 1], sl2, -lq4[j + 1]) - kmask);
-            float m0 = 1.f, m1 = 1.f;
-            if (DROP) drop_pair_k(dk_u + (uint32_t)((qb * 32 + 8 * g4 + j) >> 1) * kDropC1, k_odd, p.drop_thresh, p.keep_scale, m0, m1);
-            s[i] = p0 * m0;
-            s[i + 1] = p1 * m1;
-            dp[i] = p0 * (dp[i] * m0 - dq4[j]);
-            dp[i + 1] = p1 * (dp[i + 1] * m1 - dq4[j + 1]);
-            if (bgrad) ck += dp[i] + dp[i + 1];
-          }
-        }
-        mma_acc<D>(tdo, PITCH, qb * 32, s, dv, lane);
-        mma_acc<D>(tq, PITCH, qb * 32, dp, dk, lane);
-      }
-      if (bgrad) {
-        ck = xhalf_sum(ck);
-        if (h == 0) coef[key] = f32_to_bf16(ck);
-      }
-    }
-    if (key < lk) {
-      T* dkg = static_cast<T*>(p.dk) + (kbase + key) * p.dk_stride + hd * D;
-      T* dvg = static_cast<T*>(p.dv) + (kbase + key) * p.dv_stride + hd * D;
-#pragma unroll
-      for (int d = 0; d < DB; ++d) {
-        store_t<T>(dkg + d * 32, dk[d], p.scale, h);
-        store_t<T>(dvg + d * 32, dv[d], 1.f, h);
-      }
-    }
-  }
-  // ---- bias gradients: column sums of this workgroup's dQ, dK, dV rows, WITHOUT a cross-lane reduction ----------
-  //   sum_q dQ[q,:] = scale * sum_k c_k K[k,:],  c_k = sum_q dS[q,k]          sum_k dV[k,:] = sum_q pm_q dO[q,:],  pm_q = sum_k P'[q,k]
-  //   sum_k dK[k,:] = scale * sum_q (sum_k dS[q,k]) Q[q,:] = 0: the rows of dS sum to zero (a key bias shifts every score of
-  //   a query alike and the softmax does not see it; the reference's autograd returns rounding noise of order 1e-8 there).
-  // Two matrix-vector products with tiles that are already in LDS: tile^T on the MFMA A side (ds_read_b64_tr_b16), the
-  // coefficient vector broadcast on the B side; one (tensor, 32-column block) unit per wave.
-  if (bgrad) {
-    __syncthreads();                                       // coefficients of every wave are in LDS
-    float* outp = p.dbias_part + (b * 3 * p.h + hd) * D;
-    for (int u = w; u < 2 * DB; u += R / 32) {             // wave-uniform
-      const int t = u / DB, db = u % DB;                   // t = 0: dQ sums from (K tile, c), t = 1: dV sums from (dO tile, pm)
-      const T* tile = (t == 0 ? tk : tdo) + db * 32;
-      const T* cf = coef + t * R;
-      const int rows = t == 0 ? lk : lq;
-      f32x16 acc[1];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[0][i] = 0.f;
-#pragma unroll
-      for (int rb = 0; rb < R / 32; ++rb) {
-        if (rb * 32 >= rows) break;
-        mma_acc_coef<32>(tile, PITCH, rb * 32, cf, acc, lane);
-      }
-      if (r == 0) {                                        // every column holds the same vector: column 0 of each half writes its rows
-        const float mul = t == 0 ? p.scale : 1.f;
-        float* o2 = outp + (t == 0 ? 0 : 2) * p.h * D + db * 32;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o2[acc_row(i, h)] = acc[0][i] * mul;
-      }
-    }
-    if (tid < D) outp[p.h * D + tid] = 0.f;               // dK column sums
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward, sequences of <= 128 tokens (bf16): ONE workgroup per (sequence, head), Q / K / V resident in LDS (same
-// staging as attn_bwd_short_kernel: coalesced 16-byte pieces, all loads in flight at once, one barrier, operand
-// fragments from LDS).  All keys of the sequence are present, so the softmax is two plain passes over the score
-// blocks held in registers (row max, then exp / sum): no running rescale.
-// ------------------------------------------------------------------------------------------------
-template <int D, bool DROP, int R>
-__global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
-  using T = bf16_t;
-  static_assert(D == 64, "dense swizzled images are laid out for d = 64");
-  constexpr int NT = 2 * R, PITCH = D, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;   // dense rows: 48 KB at R = 128 = three workgroups per CU
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* tk = reinterpret_cast<T*>(smem_raw);
-  T* tv = tk + R * PITCH;
-  T* tq = tv + R * PITCH;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int64_t b = blockIdx.x / p.h, hd = blockIdx.x % p.h;
-  int64_t lq_, lk_, qbase, kbase, lse_base;
-  seq_view(p, b, hd, lq_, lk_, qbase, kbase, lse_base);
-  int64_t kvlen = lk_;
-  if (p.kv_len) { kvlen = p.kv_len[b]; if (kvlen > lk_) kvlen = lk_; if (kvlen < 0) kvlen = 0; }
-  const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
-  const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
-  const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
-  const int lq = (int)lq_, lk = (int)lk_, kvl = (int)kvlen;
-  uint4 rk[PER], rv[PER], rq[PER];
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
-    rk[k] = rv[k] = rq[k] = make_uint4(0, 0, 0, 0);
-    if (row < lk) {
-      rk[k] = *reinterpret_cast<const uint4*>(kg + (uint32_t)(row * (int)p.k_stride + col));
-      rv[k] = *reinterpret_cast<const uint4*>(vg + (uint32_t)(row * (int)p.v_stride + col));
-    }
-    if (row < lq) rq[k] = *reinterpret_cast<const uint4*>(qg + (uint32_t)(row * (int)p.q_stride + col));
-  }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    const int i = tid + k * NT, row = i / CPR;
-    const int c = i % CPR;                                      // 16-byte chunk of the row -> swizzled slot (attn_common.hpp)
-    *reinterpret_cast<uint4*>(tk + row * PITCH + ((c ^ sw_row(row)) << 3)) = rk[k];
-    *reinterpret_cast<uint4*>(tv + row * PITCH + ((c ^ sw_tr(row)) << 3)) = rv[k];
-    *reinterpret_cast<uint4*>(tq + row * PITCH + ((c ^ sw_row(row)) << 3)) = rq[k];
-  }
-  __syncthreads();
-  if (w * 32 >= lq) return;                                   // (no barrier below)
-  const int q_row = w * 32 + r;
-  RowFrag<T, D> qf;
-#pragma unroll
-  for (int s = 0; s < D / 16; ++s) qf.v[s] = *reinterpret_cast<const bf16x8*>(tq + q_row * PITCH + (((2 * s + h) ^ sw_row(q_row)) << 3));
-  const float sl2 = p.scale * kLog2e;
-  const int nblk = (kvl + 31) / 32;                           // block-uniform
-  f32x16 s[NB];
-  float rmax = -INFINITY;
-#pragma unroll
-  for (int kb = 0; kb < NB; ++kb) {
-    if (kb >= nblk) break;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-    mma_rows_sw(tk, kb * 32, qf, s[kb], r, h);
-    if ((kb + 1) * 32 > kvl) {                                // the block that straddles kv_len
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = kb * 32 + acc_row(i, h) < kvl ? s[kb][i] : -INFINITY;
-    }
-    rmax = fmaxf(rmax, max16(s[kb]));
-  }
-  const float m = nblk > 0 ? xhalf_max(rmax) * sl2 : 0.f;    // finite when any key is valid
-  const uint32_t dq_u = drop_base(attn_seed(p), lse_base) + (uint32_t)(q_row >> 1) * kDropC1 + (uint32_t)(2 * h) * kDropC2;
-  const int q_odd = q_row & 1;
-  f32x16 o[DB];
-#pragma unroll
-  for (int d = 0; d < DB; ++d)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[d][i] = 0.f;
-  float l = 0.f;
-#pragma unroll
-  for (int kb = 0; kb < NB; ++kb) {
-    if (kb >= nblk) break;
-#pragma unroll
-    for (int i = 0; i < 16; i += 2) {
-      const float e0 = fast_exp2(fmaf(s[kb][i], sl2, -m)), e1 = fast_exp2(fmaf(s[kb][i + 1], sl2, -m));   // masked: exp2(-inf) = 0
-      l += e0 + e1;                                           // the normaliser uses the un-dropped probabilities
-      float m0 = 1.f, m1 = 1.f;
-      if (DROP) drop_pair_q(dq_u + (uint32_t)((kb * 32 + acc_row(i, 0)) >> 1) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
-      s[kb][i] = e0 * m0;
-      s[kb][i + 1] = e1 * m1;
-    }
-    mma_acc_sw(tv, kb * 32, s[kb], o, lane);
-  }
-  l = xhalf_sum(l);
-  if (q_row < lq) {
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
-#pragma unroll
-    for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);
-    if (h == 0 && p.lse_w) p.lse_w[lse_base + q_row] = l > 0.f ? (m + __log2f(l)) * kLn2 : -INFINITY;
-  }
-}
-
 // 8-bit dropout threshold: P(drop) = th / 256 (|error| <= 2e-3: 0.1 -> 0.1016, 0.3 -> 0.3008), keep scale uses the quantised rate
 static inline uint32_t drop8(float p) { long t = lroundf(p * 256.f); return (uint32_t)(t < 0 ? 0 : (t > 255 ? 255 : t)); }
 
@@ -911,7 +589,11 @@ using namespace gmlm;
 // per flop fall with the number of query rows that share a tile: 8 waves = 256 rows for long sequences when there
 // are enough workgroups to fill the chip twice (measured: forward neutral, backward +4 % at N = 20k); 4 waves
 // (128 rows) by default; 2 waves (64 rows) when the grid would under-fill the 256 CUs (+80 % at N = 5k).
-namespace gmlm { int attn_fwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t bh, hipStream_t st); }
+namespace gmlm {
+int attn_fwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t bh, hipStream_t st);
+int attn_short_fwd_launch(const AttnParams& p, int64_t rows, int64_t items, hipStream_t st);
+int attn_short_bwd_launch(const AttnParams& p, int64_t rows, int64_t items, float* dbias, hipStream_t st);
+}
 
 static inline int pick_waves(int64_t rows, int64_t bh) {
   if (rows >= 2048 && cdiv(rows, 256) * bh >= 512) return 8;
@@ -925,9 +607,12 @@ extern "C" void gmlm_debug_set_stamp_buffer(void* p) { g_stamp_buffer = p; }
 
 extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                                   int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                                  float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, float* lse, int dtype,
-                                  const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream) {
+                                  float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, void* out_lo, float* lse,
+                                  int dtype, const int32_t* cu_seqlens, int64_t max_len, const int32_t* seq_groups, int64_t num_groups,
+                                  gmlm_stream_t stream) {
   int rc = attn_check("attention_fwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE(!seq_groups || (cu_seqlens && num_groups > 0 && num_groups <= b), "attention_fwd: seq_groups needs packed mode and 0 < num_groups <= b");
+  GMLM_REQUIRE(!out_lo || (dtype == GMLM_BF16 && aligned16(out_lo)), "attention_fwd: out_lo is the bf16 residual of a bf16 output (16-byte aligned)");
   GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_fwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
   GMLM_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "attention_fwd: dropout_p must be in [0,1)");
   GMLM_REQUIRE(scale > 0.f, "attention_fwd: scale must be positive");
@@ -940,7 +625,7 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   }
   GMLM_REQUIRE(out && aligned16(out), "attention_fwd: null or misaligned out");
   AttnParams p{};
-  p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.lse_w = lse; p.cu = cu_seqlens;
+  p.q = q; p.k = k; p.v = v; p.kv_len = kv_len; p.o_w = out; p.o_lo_w = out_lo; p.lse_w = lse; p.cu = cu_seqlens; p.groups = seq_groups;
   const int64_t rows_q = cu_seqlens ? max_len : lq;
   p.b = b; p.h = h; p.lq = lq; p.lk = lk; p.q_stride = q_stride; p.k_stride = k_stride; p.v_stride = v_stride;
   p.scale = scale;
@@ -950,29 +635,10 @@ extern "C" int gmlm_attention_fwd(const void* q, const void* k, const void* v, c
   p.delta = static_cast<float*>(g_stamp_buffer);
 #endif
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && (cu_seqlens ? max_len : lk) <= 128 && b * h >= 512) {
-    // short sequences, enough of them to fill the chip: Q / K / V resident in LDS, one barrier (attn_fwd_short_kernel)
-    static PerDeviceOnce once;
-    auto lds_of = [](int r) { return (size_t)3 * r * 64 * sizeof(bf16_t); };        // dense swizzled Q / K / V images
-    rc = once([&]() -> int {
-#define GMLM_SHORT_ATTR(RR)                                                                                                        \
-      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
-      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_short_kernel<64, false, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR)));
-      GMLM_SHORT_ATTR(32) GMLM_SHORT_ATTR(64) GMLM_SHORT_ATTR(96) GMLM_SHORT_ATTR(128)
-#undef GMLM_SHORT_ATTR
-      return GMLM_OK;
-    });
-    if (rc != GMLM_OK) return rc;
+    // short sequences, enough of them to fill the chip: Q / K / V resident in LDS, one barrier (attn_short.hip); with
+    // `seq_groups` a workgroup takes a run of sequences (<= 128 rows) instead of one
     const int64_t rk_ = cu_seqlens ? max_len : lk, rmax = rows_q > rk_ ? rows_q : rk_;
-    const int top = (int)((rmax + 31) / 32) * 32;
-#define GMLM_SHORT_LAUNCH(RR)                                                                                                      \
-    if (RR == top) {                                                                                                               \
-      if (p.drop_thresh) attn_fwd_short_kernel<64, true, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                   \
-      else attn_fwd_short_kernel<64, false, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                                 \
-    }
-    GMLM_SHORT_LAUNCH(128) GMLM_SHORT_LAUNCH(96) GMLM_SHORT_LAUNCH(64) GMLM_SHORT_LAUNCH(32)
-#undef GMLM_SHORT_LAUNCH
-    GMLM_LAUNCH_CHECK();
-    return GMLM_OK;
+    return attn_short_fwd_launch(p, seq_groups ? 128 : rmax, seq_groups ? num_groups : b, st);
   }
   if (dtype == GMLM_BF16 && (d == 96 || rows_q > 128)) {
     // software-pipelined LDS-DMA kernel (attn_fwd_pipe.hip): CrossAttention geometry (d = 96: +40-45 % at N = 5k-20k
@@ -1010,8 +676,10 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
                                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                                   int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                                   void* workspace, size_t workspace_bytes, float* dbias_partial, float* dbias,
-                                  gmlm_stream_t stream) {
+                                  const void* out_lo, const int32_t* seq_groups, int64_t num_groups, gmlm_stream_t stream) {
   int rc = attn_check("attention_bwd", b, h, lq, lk, d, dtype);
+  GMLM_REQUIRE(!seq_groups || (cu_seqlens && num_groups > 0 && num_groups <= b), "attention_bwd: seq_groups needs packed mode and 0 < num_groups <= b");
+  GMLM_REQUIRE(!out_lo || (dtype == GMLM_BF16 && aligned16(out_lo)), "attention_bwd: out_lo is the bf16 residual of a bf16 output (16-byte aligned)");
   GMLM_REQUIRE((dbias_partial == nullptr) == (dbias == nullptr), "attention_bwd: dbias_partial and dbias come together");
   GMLM_REQUIRE(!cu_seqlens || (lq == lk && max_len > 0 && !kv_len), "attention_bwd: packed mode needs lq == lk = total rows, max_len > 0, kv_len NULL");
   if (rc != GMLM_OK) return rc;
@@ -1029,7 +697,7 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
                "attention_bwd: workspace too small");
   hipStream_t st = as_stream(stream);
   AttnParams p{};
-  p.q = q; p.k = k; p.v = v; p.out = out; p.dout = dout; p.lse = lse; p.kv_len = kv_len; p.cu = cu_seqlens;
+  p.q = q; p.k = k; p.v = v; p.out = out; p.out_lo = out_lo; p.dout = dout; p.lse = lse; p.kv_len = kv_len; p.cu = cu_seqlens; p.groups = seq_groups;
   const int64_t rows_q = cu_seqlens ? max_len : lq, rows_k = cu_seqlens ? max_len : lk;
   const int64_t nb = cu_seqlens ? 1 : b;        // delta kernel: packed tensors are one [total_rows, h, d] block
   p.delta = static_cast<float*>(workspace);
@@ -1038,34 +706,9 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   p.dq_stride = dq_stride; p.dk_stride = dk_stride; p.dv_stride = dv_stride; p.scale = scale;
   p.drop_thresh = drop8(dropout_p); p.keep_scale = 256.f / (256.f - (float)p.drop_thresh); p.seed = seed; p.seed_dev = seed_dev;
   if (dtype == GMLM_BF16 && d == 64 && rows_q <= 128 && rows_k <= 128 && b * h >= 512) {
-    // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace
-    static PerDeviceOnce once;
-    auto lds_of = [](int r) { return (size_t)4 * r * (64 + 8) * sizeof(bf16_t) + 2 * r * sizeof(float) + 2 * r * sizeof(bf16_t); };   // K, V, Q, dO images + lse, delta + bias-gradient coefficients
-    rc = once([&]() -> int {
-#define GMLM_SHORT_ATTR(RR)                                                                                                        \
-      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, true, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR))); \
-      GMLM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_short_kernel<64, false, RR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(RR)));
-      GMLM_SHORT_ATTR(32) GMLM_SHORT_ATTR(64) GMLM_SHORT_ATTR(96) GMLM_SHORT_ATTR(128)
-#undef GMLM_SHORT_ATTR
-      return GMLM_OK;
-    });
-    if (rc != GMLM_OK) return rc;
+    // short sequences, enough of them to fill the chip: one fused launch (delta + dQ + dK/dV), no workspace, O is not read
     const int64_t rmax = rows_q > rows_k ? rows_q : rows_k;
-    const int top = (int)((rmax + 31) / 32) * 32;
-#define GMLM_SHORT_LAUNCH(RR)                                                                                                      \
-    if (RR == top) {                                                                                                               \
-      if (p.drop_thresh) attn_bwd_short_kernel<64, true, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                   \
-      else attn_bwd_short_kernel<64, false, RR><<<(unsigned)(b * h), 2 * RR, lds_of(RR), st>>>(p);                                 \
-    }
-    GMLM_SHORT_LAUNCH(128) GMLM_SHORT_LAUNCH(96) GMLM_SHORT_LAUNCH(64) GMLM_SHORT_LAUNCH(32)
-#undef GMLM_SHORT_LAUNCH
-    GMLM_LAUNCH_CHECK();
-    if (dbias) {                                           // [sequences, 3 h d] partial column sums -> [3 h d], fixed order
-      const int64_t width = 3 * h * d;
-      rows_sum_kernel<<<(unsigned)cdiv(width, 32), 256, 0, st>>>(dbias_partial, (int)b, width, dbias, 1.f);
-      GMLM_LAUNCH_CHECK();
-    }
-    return GMLM_OK;
+    return attn_short_bwd_launch(p, seq_groups ? 128 : rmax, seq_groups ? num_groups : b, dbias, st);
   }
   GMLM_REQUIRE(!dbias, "attention_bwd: the fused bias-gradient sums exist only on the short-sequence path (bf16, d = 64, <= 128 rows, b*h >= 512)");
   const int64_t rows = nb * lq * h;
@@ -1074,9 +717,9 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     const int lanes = cpr <= 8 ? 8 : (cpr <= 16 ? 16 : 32);
     const int64_t threads = rows * lanes;
     if (dtype == GMLM_BF16)
-      attn_delta_kernel<bf16_t><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)dout, rows, (int)d, lq, h, p.delta);
+      attn_delta_kernel<bf16_t><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const bf16_t*)out, (const bf16_t*)out_lo, (const bf16_t*)dout, rows, (int)d, lq, h, p.delta);
     else
-      attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, (const float*)dout, rows, (int)d, lq, h, p.delta);
+      attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, nullptr, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
   if (pick_waves(rows_q, b * h) == 8) {

@@ -292,6 +292,9 @@ class _RingAttention(torch.autograd.Function):
                 pend.wait()
                 cur = nxt
         out = o_acc.view(b, n, c).to(q.dtype)
+        # the merged output exists in fp32 here: keep its rounding residual for the backward's delta = rowsum(dO * O) (the
+        # 2^-9 error of the stored output alone does not cancel in dS = P (dP - delta))
+        ctx.out_lo = (o_acc.view(b, n, c) - out.to(acc_t)).to(q.dtype) if out.dtype != acc_t else None
         ctx.save_for_backward(q, kv, out, lse_acc)
         ctx.cfg = (part, h, block, seed, sizes, mx)
         return out
@@ -310,6 +313,7 @@ class _RingAttention(torch.autograd.Function):
         dq = torch.zeros(b, n, c, dtype=acc_t, device=q.device)
         nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
         lse32 = lse.to(torch.promote_types(lse.dtype, torch.float32))
+        lo_kw = {"out_lo": ctx.out_lo} if ctx.out_lo is not None else {}
         pend_d, dnxt = None, None
         for s in range(world):
             owner = (rank - s) % world
@@ -318,7 +322,7 @@ class _RingAttention(torch.autograd.Function):
                 nxt = torch.empty_like(cur)
                 pend = _exchange(cur, nxt, nxt_rank, prv_rank, group)
             kv_len = torch.full((b,), sizes[owner], dtype=torch.int32, device=q.device)
-            dq_j, dk_j, dv_j = block.bwd(q, cur[..., :c], cur[..., c:], out, dout, lse32, kv_len, seed + owner)
+            dq_j, dk_j, dv_j = block.bwd(q, cur[..., :c], cur[..., c:], out, dout, lse32, kv_len, seed + owner, **lo_kw)
             # the accumulator of THIS block left the previous rank while this block's arithmetic ran (posted at the end
             # of the previous step): its hop is hidden, only now is it needed
             if pend_d is not None:

@@ -270,9 +270,16 @@ class GraphTextLM(nn.Module):
                     if pad:
                         tok = torch.cat([tok, tok.new_zeros(pad)])
                         pos = torch.cat([pos, torch.arange(pad, device=dev)])
+                    # short sequences (the reference tokenises to <= 128 tokens, main.py:340): consecutive sequences are packed
+                    # into attention work items of <= 128 rows (host arithmetic on the host copy of the lengths, ~0.2 ms per
+                    # 1,000 sequences, once per batch: all layers, forward and backward, share it)
+                    groups = None
+                    n_seq = bi.numel() + (1 if pad else 0)
+                    if cd == torch.bfloat16 and p // heads == 64 and lmax <= 128 and n_seq * heads >= 512:
+                        groups = to_dev(ops.pack_sequence_groups(lh.tolist() + ([pad] if pad else [])))
                     hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu_all, lmax, cd, self.plm_encoder.training,
                                                  self.plm_gradient_checkpointing, weights,
-                                                 pair_count=float((lh.double() ** 2).sum()) + float(pad * pad))
+                                                 pair_count=float((lh.double() ** 2).sum()) + float(pad * pad), groups=groups)
                     plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, None, bi, cu, total)
                 else:
                     ids = tokens.input_ids[bi, :lmax]

@@ -354,6 +354,12 @@ def _rows_view(t: torch.Tensor, h: int, d: int):
     return t.stride(1)
 
 
+def _short_path(dtype, d: int, rows: int, pairs: int) -> bool:
+    """Same condition as the C entries: bf16, d = 64, every sequence <= 128 rows, >= 512 (sequence, head) pairs -> the
+    LDS-resident short-sequence kernels (their backward forms delta itself and needs neither ``out`` nor ``out_lo``)."""
+    return dtype == torch.bfloat16 and d == 64 and rows <= 128 and pairs >= 512
+
+
 class Attention(torch.autograd.Function):
     """out[b, lq, h*d] = softmax(q k^T * scale + key-padding mask) v with streaming softmax.
 
@@ -370,17 +376,22 @@ class Attention(torch.autograd.Function):
         qs, ks, vs = _rows_view(q, h, d), _rows_view(k, h, d), _rows_view(v, h, d)
         out = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
         lse = torch.empty(b, h, lq, dtype=torch.float32, device=q.device)
+        # bf16 streaming path: keep the rounding residual of the output for the backward's delta (gmlm_hip.h, out_lo)
+        want_lo = q.dtype == torch.bfloat16 and not _short_path(q.dtype, d, max(lq, lk), b * h) and \
+            any(t.requires_grad for t in (q, k, v))
+        out_lo = torch.empty_like(out) if want_lo else None
         with _span("attn_fwd_d%d" % d, flops=4.0 * b * h * lq * lk * d):
             sd = ctx.sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, lq, lk, d, qs, ks, vs, float(scale),
-                                           float(p), seed, sd, _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
-        ctx.save_for_backward(q, k, v, out, lse, kv_len)
+                                           float(p), seed, sd, _ptr(out), _ptr(out_lo), _ptr(lse), _dt(q), None, 0, None, 0, _stream()),
+                  "gmlm_attention_fwd")
+        ctx.save_for_backward(q, k, v, out, lse, kv_len, out_lo)
         ctx.cfg = (h, float(scale), float(p), seed)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        q, k, v, out, lse, kv_len = ctx.saved_tensors
+        q, k, v, out, lse, kv_len, out_lo = ctx.saved_tensors
         h, scale, p, seed = ctx.cfg
         b, lq, hd = q.shape
         lk = k.shape[1]
@@ -395,7 +406,8 @@ class Attention(torch.autograd.Function):
             sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            lq, lk, d, q.stride(1), k.stride(1), v.stride(1), scale, p, seed, sd, _ptr(dq),
-                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), None, None, _stream()),
+                                           _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0, _ptr(ws), ws.numel(), None, None,
+                                           _ptr(out_lo), None, 0, _stream()),
                   "gmlm_attention_bwd")
         return dq, dk, dv, None, None, None, None, None
 
@@ -411,10 +423,12 @@ class AttentionQKV(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len, pair_count=None, *bias_masters):
+    def forward(ctx, qkv, kv_len, h, scale, p, seed, cu_seqlens, max_len, pair_count=None, groups=None, *bias_masters):
         """``bias_masters``: optional (q, k, v) bias parameters of the fused projection that produced ``qkv``.  Their values
         are not read (the projection has added them); they are inputs so that backward can RETURN their gradient, the
-        column sums of dqkv, which the short-sequence kernel forms in-kernel (otherwise one reduction pass here)."""
+        column sums of dqkv, which the short-sequence kernel forms in-kernel (otherwise one reduction pass here).
+        ``groups`` (packed mode): int32 [G + 1] device tensor; work item g of the short-sequence kernels = sequences
+        [groups[g], groups[g+1]) - at most 13 sequences / 128 rows (``pack_sequence_groups``)."""
         _cuda(qkv)
         qkv = qkv.contiguous()
         packed = cu_seqlens is not None
@@ -430,21 +444,35 @@ class AttentionQKV(torch.autograd.Function):
         lse = torch.empty((h, l) if packed else (b, h, l), dtype=torch.float32, device=qkv.device)
         # packed: exact sum of len^2 when the caller knows it (host copy of the lengths), else the bound max_len * rows
         flops = 4.0 * h * d * ((float(pair_count) if pair_count else float(max_len) * l) if packed else float(b) * l * l)
+        rows = int(max_len) if packed else l
+        short = _short_path(qkv.dtype, d, rows, b * h)
+        if groups is not None and not (packed and short):
+            groups = None                                       # only the short-sequence kernels pack sequences into work items
+        n_groups = 0 if groups is None else groups.numel() - 1
+        out_lo = torch.empty_like(out) if (qkv.dtype == torch.bfloat16 and not short and qkv.requires_grad) else None
         with _span("attn_fwd_d%d" % d, flops=flops):
             sd = ctx.sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
-                                           float(p), seed, sd, _ptr(out), _ptr(lse), _dt(qkv), _ptr(cu_seqlens), int(max_len),
-                                           _stream()), "gmlm_attention_fwd")
-        ctx.save_for_backward(qkv, out, lse, kv_len, cu_seqlens)
+                                           float(p), seed, sd, _ptr(out), _ptr(out_lo), _ptr(lse), _dt(qkv), _ptr(cu_seqlens),
+                                           int(max_len), _ptr(groups), n_groups, _stream()), "gmlm_attention_fwd")
+        if short:
+            ctx.save_for_backward(qkv, lse, kv_len, cu_seqlens, groups)        # the fused backward never reads the forward output
+        else:
+            ctx.save_for_backward(qkv, lse, kv_len, cu_seqlens, groups, out, out_lo)
+        ctx.short = short
         ctx.cfg = (h, float(scale), float(p), seed, int(max_len), b, l, flops)
         ctx.bias_shapes = [(m.shape[0], m.dtype) for m in bias_masters]
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        qkv, out, lse, kv_len, cu_seqlens = ctx.saved_tensors
+        if ctx.short:
+            qkv, lse, kv_len, cu_seqlens, groups = ctx.saved_tensors
+            out, out_lo = gout, None                            # placeholder pointer: not read on this path
+        else:
+            qkv, lse, kv_len, cu_seqlens, groups, out, out_lo = ctx.saved_tensors
         h, scale, p, seed, max_len, b, l, flops = ctx.cfg
-        want_db = bool(ctx.bias_shapes) and any(ctx.needs_input_grad[9:])
+        want_db = bool(ctx.bias_shapes) and any(ctx.needs_input_grad[10:])
         hd3 = qkv.shape[-1]
         hd = hd3 // 3
         d = hd // h
@@ -456,17 +484,18 @@ class AttentionQKV(torch.autograd.Function):
         # short-sequence path (one launch per (sequence, head): same condition as the C entry): the column sums of dqkv --
         # the bias gradient of the fused QKV projection that produced qkv -- come out of the kernel as well
         rows = max_len if cu_seqlens is not None else l
-        fused_db = want_db and qkv.dtype == torch.bfloat16 and d == 64 and rows <= 128 and b * h >= 512
+        fused_db = want_db and ctx.short
+        n_groups = 0 if groups is None else groups.numel() - 1
         part = db = None
         if fused_db:
-            part = _ws(4 * b * hd3, qkv.device).view(torch.float32)
+            part = _ws(4 * (n_groups or b) * hd3, qkv.device).view(torch.float32)
             db = torch.empty(hd3, dtype=torch.float32, device=qkv.device)
         with _span("attn_bwd_d%d" % d, flops=2.5 * flops):
             sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            l, l, d, hd3, hd3, hd3, scale, p, seed, sd, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
                                            hd3, _dt(qkv), _ptr(cu_seqlens), max_len, _ptr(ws), ws.numel(), _ptr(part), _ptr(db),
-                                           _stream()),
+                                           _ptr(out_lo), _ptr(groups), n_groups, _stream()),
                   "gmlm_attention_bwd")
         dbs = ()
         if want_db:
@@ -474,7 +503,7 @@ class AttentionQKV(torch.autograd.Function):
                 db = dqkv.reshape(-1, hd3).sum(0, dtype=torch.float32)
             dbs = tuple(g if g.dtype == dt_ else g.to(dt_)
                         for g, (_, dt_) in zip(db.split([n_ for n_, _ in ctx.bias_shapes], 0), ctx.bias_shapes))
-        return (dqkv, None, None, None, None, None, None, None, None, *dbs)
+        return (dqkv, None, None, None, None, None, None, None, None, None, *dbs)
 
 
 class AttentionBlock:
@@ -497,10 +526,12 @@ class AttentionBlock:
             sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, self.h, lq, lk, d, _rows_view(q, self.h, d),
                                            _rows_view(k, self.h, d), _rows_view(v, self.h, d), self.scale, self.p, int(seed), sd,
-                                           _ptr(out), _ptr(lse), _dt(q), None, 0, _stream()), "gmlm_attention_fwd")
+                                           _ptr(out), None, _ptr(lse), _dt(q), None, 0, None, 0, _stream()), "gmlm_attention_fwd")
         return out, lse
 
-    def bwd(self, q, k, v, out, dout, lse, kv_len, seed):
+    def bwd(self, q, k, v, out, dout, lse, kv_len, seed, out_lo=None):
+        """``out_lo``: optional bf16 residual of the (global) output, O = out + out_lo (the ring merges its blocks in fp32 and
+        knows it): delta then has fp32-like accuracy."""
         b, lq, hd = q.shape
         lk, d = k.shape[1], hd // self.h
         dq = torch.empty(b, lq, hd, dtype=q.dtype, device=q.device)
@@ -513,15 +544,36 @@ class AttentionBlock:
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), _ptr(kv_len), b, self.h,
                                            lq, lk, d, _rows_view(q, self.h, d), _rows_view(k, self.h, d), _rows_view(v, self.h, d),
                                            self.scale, self.p, int(seed), sd, _ptr(dq), _ptr(dk), _ptr(dv), hd, hd, hd, _dt(q), None, 0,
-                                           _ptr(ws), ws.numel(), None, None, _stream()), "gmlm_attention_bwd")
+                                           _ptr(ws), ws.numel(), None, None, _ptr(out_lo), None, 0, _stream()), "gmlm_attention_bwd")
         return dq, dk, dv
 
 
 def attention_qkv(qkv, kv_len, num_heads, scale, dropout_p=0.0, training=False, cu_seqlens=None, max_len=0, pair_count=None,
-                  bias_masters=()):
+                  bias_masters=(), groups=None):
     p = float(dropout_p) if training else 0.0
     return AttentionQKV.apply(qkv, kv_len, num_heads, scale, p, draw_seed() if p > 0 else 0, cu_seqlens, max_len, pair_count,
-                              *bias_masters)
+                              groups, *bias_masters)
+
+
+SHORT_GROUP_ROWS, SHORT_GROUP_SEQS = 128, 13
+
+
+def pack_sequence_groups(lens) -> torch.Tensor:
+    """Greedy packing of CONSECUTIVE sequences into work items of the short-sequence attention kernels: a group takes
+    sequences while its rows stay <= 128 and its count <= 13 (gmlm_hip.h, seq_groups).  ``lens``: host sequence of ints
+    (every length <= 128).  Returns the int32 [G + 1] boundaries (host tensor)."""
+    bounds, rows, cnt = [0], 0, 0
+    for i, n in enumerate(lens):
+        n = int(n)
+        if n > SHORT_GROUP_ROWS:
+            raise ValueError(f"sequence {i} has {n} rows: the short-sequence kernels take <= {SHORT_GROUP_ROWS}")
+        if cnt and (rows + n > SHORT_GROUP_ROWS or cnt == SHORT_GROUP_SEQS):
+            bounds.append(i)
+            rows = cnt = 0
+        rows += n
+        cnt += 1
+    bounds.append(len(lens))
+    return torch.tensor(bounds, dtype=torch.int32)
 
 
 def attention(q, k, v, kv_len, num_heads, scale, dropout_p=0.0, training=False):

@@ -191,14 +191,23 @@ int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const float* bias
  * dropout_p > 0 drops attention probabilities (after normalisation, scaled by 1/(1-p)) exactly like
  * nn.Dropout on `attn` in main.py:161 / hf eager attention; the mask is hash(seed, (b,h,q,key)) and
  * is regenerated, not stored, by the backward pass when given the same seed.
- * Backward: bf16, d = 64, every sequence <= 128 rows (lq, lk <= 128, or max_len <= 128 in packed mode) and
- * b*h >= 512 runs as ONE launch per (sequence, head) (delta + dQ + dK/dV from one LDS image); everything else
- * as three launches (delta, dQ, dK/dV).  Same results either way up to the summation order inside delta.
+ * Short sequences: bf16, d = 64, every sequence <= 128 rows (lq, lk <= 128, or max_len <= 128 in packed mode) and
+ * b*h >= 512 runs with Q / K / V (/ dO) of a work item resident in LDS; the backward is ONE launch (delta + dQ + dK/dV)
+ * that forms delta = sum_k P dP from its own fp32 P, dP (it does not read `out`); everything else runs the streaming
+ * forward and three backward launches (delta = rowsum(dO * O), dQ, dK/dV).
+ * seq_groups (packed mode, optional; int32 [num_groups + 1], device): work item g of the short-sequence kernels is the run
+ * of sequences [seq_groups[g], seq_groups[g+1]) - at most 13 sequences and 128 rows in total (the caller guarantees both;
+ * rows past 128 would be ignored) - attended block-diagonally.  Ignored by the streaming kernels.
+ * out_lo (bf16 only, optional): the forward also stores lo = bf16(O - bf16(O)); handed to the backward, delta is formed
+ * from out + out_lo, i.e. with fp32-like accuracy.  With `out` alone delta carries the 2^-9 rounding of the stored
+ * output, which does NOT cancel in dS = P (dP - delta) and dominates the query / key gradients whenever those are small
+ * against |dO||O| (deep encoder layers).  The short-sequence kernels neither write nor need it.
  * ------------------------------------------------------------------------------------------- */
 int gmlm_attention_fwd(const void* q, const void* k, const void* v, const int32_t* kv_len, int64_t b, int64_t h,
                        int64_t lq, int64_t lk, int64_t d, int64_t q_stride, int64_t k_stride, int64_t v_stride,
-                       float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, float* lse, int dtype,
-                       const int32_t* cu_seqlens, int64_t max_len, gmlm_stream_t stream);
+                       float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* out, void* out_lo, float* lse,
+                       int dtype, const int32_t* cu_seqlens, int64_t max_len, const int32_t* seq_groups, int64_t num_groups,
+                       gmlm_stream_t stream);
 /* packed mode: pass b = 1 (delta is [h, total_rows]) */
 size_t gmlm_attention_bwd_workspace_bytes(int64_t b, int64_t h, int64_t lq, int64_t lk, int64_t d);
 int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
@@ -207,8 +216,8 @@ int gmlm_attention_bwd(const void* q, const void* k, const void* v, const void* 
                        float dropout_p, uint64_t seed, const uint64_t* seed_dev, void* dq, void* dk, void* dv, int64_t dq_stride,
                        int64_t dk_stride, int64_t dv_stride, int dtype, const int32_t* cu_seqlens, int64_t max_len,
                        void* workspace, size_t workspace_bytes,
-                       float* dbias_partial /* [b, 3*h*d] scratch */, float* dbias /* [3*h*d]: column sums of dq | dk | dv over all rows */,
-                       gmlm_stream_t stream);
+                       float* dbias_partial /* [b or num_groups, 3*h*d] scratch */, float* dbias /* [3*h*d]: column sums of dq | dk | dv over all rows */,
+                       const void* out_lo, const int32_t* seq_groups, int64_t num_groups, gmlm_stream_t stream);
 /* dbias (optional, both pointers or neither; short-sequence path only, EINVAL otherwise): the bias gradient of a fused
  * QKV projection, sum over rows of [dq | dk | dv], formed inside the backward kernel from tiles it already holds
  * (three matrix-vector products on the MFMA pipe) instead of a separate pass over dqkv. */

@@ -201,9 +201,9 @@ def graph_embeddings(om, x0, edge_index, edge_type):
 class _ShortAttention(torch.autograd.Function):
     """Forward: s = q~ k~^T (fp32); m = rowmax(s) * c, c = scale*log2e; e = exp2(fma(s, c, -m)); l = sum e (fp32, not rounded);
     o = bf16((bf16(e) v~) * (1/l)); lse = (m + log2 l) ln2.
-    Backward: delta = rowsum(do~ * o~) (fp32); p = exp2(fma(s, c, -lse*log2e)); dp = do~ v~^T; ds = p (dp - delta);
-    dq = bf16(scale * bf16(ds) k~); dk = bf16(scale * bf16(ds)^T q~); dv = bf16(bf16(p)^T do~).
-    Also returns through ``ctx`` nothing else: the fused QKV-bias sums are formed by the caller from dq / dv."""
+    Backward: p = exp2(fma(s, c, -lse*log2e)); dp = do~ v~^T; delta = sum_k p dp IN FP32 (the kernel keeps P and dP of all key
+    blocks of a query in registers; it does not read the rounded forward output); ds = p (dp - delta);
+    dq = bf16(scale * bf16(ds) k~); dk = bf16(scale * bf16(ds)^T q~); dv = bf16(bf16(p)^T do~)."""
 
     @staticmethod
     def forward(ctx, q, k, v, lens, scale):
@@ -232,9 +232,9 @@ class _ShortAttention(torch.autograd.Function):
         kmask = valid[:, None, None, :]
         qmask = valid[:, None, :, None]
         s = q @ k.transpose(-1, -2)
-        delta = (o * do).sum(-1, keepdim=True)
         p = torch.exp2(s * c - lse * LOG2E).masked_fill(~kmask, 0.0).masked_fill(~qmask, 0.0)
         dp = do @ v.transpose(-1, -2)
+        delta = (p * dp).sum(-1, keepdim=True)
         ds = r(p * (dp - delta))
         dq = r((ds @ k) * scale)
         dk = r((ds.transpose(-1, -2) @ q) * scale)
@@ -276,9 +276,10 @@ def _pipe_forward(q, k, v, scale):
         l = l * alpha + e.sum(-1)
         o = o * alpha[..., None] + r(e) @ vb
         m = m_new
-    out = r(o * (1.0 / l)[..., None])
+    of = o * (1.0 / l)[..., None]
+    out = r(of)
     lse = (m + torch.log2(l)) * LN2
-    return out, lse
+    return out, r(of - out), lse                                              # output, its bf16 rounding residual, log-sum-exp
 
 
 def _split2(x):
@@ -287,24 +288,25 @@ def _split2(x):
 
 
 class _LongAttention(torch.autograd.Function):
-    """Forward = _pipe_forward.  Backward = the delta / dQ / dK-dV kernels with the folded chains:
+    """Forward = _pipe_forward (which also keeps the bf16 residual of its output).  Backward = the delta / dQ / dK-dV kernels
+    with the folded chains; delta = rowsum(do~ * (o + o_lo)):
        dQ kernel : s = -lse_hi - lse_lo + bf16(q~ c) k~^T, p = exp2(s), dp = -d_hi - d_lo + do~ v~^T, dq = bf16(scale bf16(p dp) k~)
        dKV kernel: s = -lse_hi - lse_lo + q~ bf16(k~ c)^T, p = exp2(s), dv = bf16(bf16(p)^T do~), dk = bf16(scale bf16(p dp)^T q~)"""
 
     @staticmethod
     def forward(ctx, q, k, v, scale):
-        o, lse = _pipe_forward(q, k, v, scale)
-        ctx.save_for_backward(q, k, v, o, lse)
+        o, o_lo, lse = _pipe_forward(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, o, o_lo, lse)
         ctx.scale = scale
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, o_lo, lse = ctx.saved_tensors
         scale = ctx.scale
         c = scale * LOG2E
         do = r(do)
-        delta = (o * do).sum(-1)
+        delta = ((o + o_lo) * do).sum(-1)                                     # delta kernel: O = out + out_lo (2^-17)
         lh, ll = _split2(lse * LOG2E)
         dh, dl = _split2(delta)
         dp = (do @ v.transpose(-1, -2) - dh[..., None]) - dl[..., None]

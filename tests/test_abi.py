@@ -41,7 +41,7 @@ def test_argument_validation_happens_on_the_host(built):
     lib = built.lib()
     rc = lib.gmlm_rgcn_mean_spmm(None, 0, 4, None, None, None, 1, 10, 8, None, 8, 0, 0, None, None, None, 0, 0, None, None)   # stride < f
     assert rc == -1 and b"stride" in lib.gmlm_last_error()
-    rc = lib.gmlm_attention_fwd(None, None, None, None, 1, 8, 16, 16, 128, 1024, 1024, 1024, 1.0, 0.0, 0, None, None, None, 0, None, 0, None)
+    rc = lib.gmlm_attention_fwd(None, None, None, None, 1, 8, 16, 16, 128, 1024, 1024, 1024, 1.0, 0.0, 0, None, None, None, None, 0, None, 0, None, 0, None)
     assert rc == -1 and b"head dim" in lib.gmlm_last_error()
     rc = lib.gmlm_bias_res_layernorm_fwd(None, None, None, None, None, 4, 770, 1e-5, 0, 0.0, 0, None, None, None, None, 0, None)
     assert rc == -1 and b"multiple" in lib.gmlm_last_error()

@@ -75,7 +75,8 @@ def test_pipelined_forward_reference_max_schedule():
     h, n, d = 2, 200, 16
     q, k, v = (E.r(torch.randn(h, n, d, generator=g)) for _ in range(3))
     k[0, 150] = q[0, 5] * 9.0                                           # a late, large score for one query
-    o, lse = E._pipe_forward(q, k, v, d ** -0.5)
+    o, o_lo, lse = E._pipe_forward(q, k, v, d ** -0.5)
+    assert float(o_lo.abs().max()) <= 2 ** -8 * float(o.abs().max())
     s = (q.double() @ k.double().transpose(-1, -2)) * d ** -0.5
     ref = torch.softmax(s, -1) @ v.double()
     assert float((o.double() - ref).abs().max()) < 2e-2 * float(ref.abs().max())

@@ -565,6 +565,37 @@ def test_attention_fused_short_sequence_backward(dev):
     db_ref = gr.sum(0)
     assert float((db.cpu() - db_ref.cpu()).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
     assert float((db - qkv.grad.float().sum(0)).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
+    # the same batch with consecutive sequences PACKED into work items of <= 128 rows / <= 13 sequences (block-diagonal mask in
+    # the MFMA chain): same numbers as one sequence per work item up to the bf16 summation order of the bias sums
+    from gmlm_amd.ops import pack_sequence_groups
+    grp = pack_sequence_groups(lens.tolist())
+    gl = (grp[1:] - grp[:-1]).tolist()
+    rows_per = [int(lens[grp[i]:grp[i + 1]].sum()) for i in range(len(gl))]
+    assert max(gl) > 1 and max(gl) <= 13 and max(rows_per) <= 128 and int(grp[-1]) == lens.numel()
+    qkv_g = qkv.detach().clone().requires_grad_(True)
+    bg = [torch.zeros(h * d, device=dev, requires_grad=True) for _ in range(3)]
+    yg = attention_qkv(qkv_g, None, h, d ** -0.5, 0.0, False, cu.to(dev), 128, bias_masters=bg, groups=grp.to(dev))
+    yg.backward(go)
+    assert torch.equal(yg, y)                                    # a row's scores, max and sum do not depend on the packing
+    for j, name in enumerate("qkv"):
+        a, r = qkv_g.grad[:, j * h * d:(j + 1) * h * d].float(), gr[:, j * h * d:(j + 1) * h * d]
+        assert float((a - r).abs().max()) <= 2e-2 * float(r.abs().max()), name
+    assert torch.equal(qkv_g.grad, qkv.grad)
+    dbg = torch.cat([t_.grad for t_ in bg])
+    assert float((dbg.cpu() - db_ref.cpu()).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
+    # 14 sequences of one token + short ones: more sequences than a group may hold (13) must split, ids stay distinct
+    lens4 = torch.tensor([1] * 30 + [3, 2, 5] * 20)
+    cu4 = torch.zeros(lens4.numel() + 1, dtype=torch.int32)
+    cu4[1:] = torch.cumsum(lens4, 0)
+    grp4 = pack_sequence_groups(lens4.tolist())
+    assert int((grp4[1:] - grp4[:-1]).max()) == 13
+    qkv4 = (torch.randn(int(cu4[-1]), 3 * h * d, generator=g) * 0.7).to(dev, torch.bfloat16).requires_grad_(True)
+    go4 = torch.randn(int(cu4[-1]), h * d, generator=g).to(dev, torch.bfloat16)
+    y4 = attention_qkv(qkv4, None, h, d ** -0.5, 0.0, False, cu4.to(dev), 5, groups=grp4.to(dev))
+    y4.backward(go4)
+    yr4, gr4 = _packed_ref_grads(qkv4.detach(), go4, lens4, h, d, d ** -0.5)
+    assert float((y4.detach().float() - yr4).abs().max()) <= 2e-2 * float(yr4.abs().max())
+    assert float((qkv4.grad.float() - gr4).abs().max()) <= 2e-2 * float(gr4.abs().max())
     # long sequences / few pairs: no in-kernel sums; the operator still returns the bias gradient (one reduction pass)
     lens3 = torch.tensor([200, 40])
     cu3 = torch.tensor([0, 200, 240], dtype=torch.int32)

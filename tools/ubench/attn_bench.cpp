@@ -74,8 +74,8 @@ int main(int argc, char** argv) {
     const float scale = 1.f / sqrtf((float)c.d);
     const uint64_t seed = 0x1234567ull;
     // exact-f32 reference (same dropout hash -> same mask)
-    GK(gmlm_attention_fwd(qf, kf, vf, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, of, lsef, GMLM_F32, nullptr, 0, nullptr));
-    if (do_bwd) GK(gmlm_attention_bwd(qf, kf, vf, of, gof, lsef, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dqf, dkf, dvf, st, st, st, GMLM_F32, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
+    GK(gmlm_attention_fwd(qf, kf, vf, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, of, nullptr, lsef, GMLM_F32, nullptr, 0, nullptr, 0, nullptr));
+    if (do_bwd) GK(gmlm_attention_bwd(qf, kf, vf, of, gof, lsef, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dqf, dkf, dvf, st, st, st, GMLM_F32, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
     CK(hipDeviceSynchronize());
     std::vector<float> ro(n), rl(rows * c.h), rdq(n), rdk(n), rdv(n);
     CK(hipMemcpy(ro.data(), of, n * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(rl.data(), lsef, rows * c.h * 4, hipMemcpyDeviceToHost));
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
     for (int var : variants) {
       setenv("GMLM_ATTN_VARIANT", std::to_string(var).c_str(), 1);
       CK(hipMemset(o, 0xFF, n * 2)); CK(hipMemset(lse, 0xFF, rows * c.h * 4));
-      GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, lse, GMLM_BF16, nullptr, 0, nullptr));
+      GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, nullptr, lse, GMLM_BF16, nullptr, 0, nullptr, 0, nullptr));
       CK(hipDeviceSynchronize());
       std::vector<uint16_t> ho(n); std::vector<float> hl(rows * c.h);
       CK(hipMemcpy(ho.data(), o, n * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(hl.data(), lse, rows * c.h * 4, hipMemcpyDeviceToHost));
@@ -99,7 +99,7 @@ int main(int argc, char** argv) {
         const size_t nwaves = (size_t)(c.l / 32 + 8) * c.b * c.h;
         uint64_t* dbg; CK(hipMalloc(&dbg, nwaves * SL * 8)); CK(hipMemset(dbg, 0, nwaves * SL * 8));
         gmlm_debug_set_stamp_buffer(dbg);
-        GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, lse, GMLM_BF16, nullptr, 0, nullptr));
+        GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, nullptr, lse, GMLM_BF16, nullptr, 0, nullptr, 0, nullptr));
         CK(hipDeviceSynchronize());
         gmlm_debug_set_stamp_buffer(nullptr);
         std::vector<uint64_t> hd(nwaves * SL); CK(hipMemcpy(hd.data(), dbg, nwaves * SL * 8, hipMemcpyDeviceToHost));
@@ -156,15 +156,15 @@ int main(int argc, char** argv) {
 #endif
       hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
       const int iters = 20;
-      for (int i = 0; i < 3; ++i) GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, lse, GMLM_BF16, nullptr, 0, nullptr));
+      for (int i = 0; i < 3; ++i) GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, nullptr, lse, GMLM_BF16, nullptr, 0, nullptr, 0, nullptr));
       CK(hipEventRecord(e0, nullptr));
-      for (int i = 0; i < iters; ++i) GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, lse, GMLM_BF16, nullptr, 0, nullptr));
+      for (int i = 0; i < iters; ++i) GK(gmlm_attention_fwd(q, k, v, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, o, nullptr, lse, GMLM_BF16, nullptr, 0, nullptr, 0, nullptr));
       CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
       printf("%-14s var=%d fwd %8.1f us  %7.1f TF/s padded (%.3f of 2.5 PF)  %7.1f TF/s executed   max|o-f32|=%.4f max|lse-f32|=%.5f nan=%ld\n",
              c.tag, var, ms * 1e3, padded / ms / 1e9, padded / ms / 1e9 / 2500.0, useful / ms / 1e9, eo, el, (long)bad);
       if (do_bwd) {
-        GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
+        GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
         CK(hipDeviceSynchronize());
         std::vector<uint16_t> g(n);
         double e3[3] = {0, 0, 0}, m3[3] = {0, 0, 0};
@@ -173,9 +173,9 @@ int main(int argc, char** argv) {
           CK(hipMemcpy(g.data(), dptr[t], n * 2, hipMemcpyDeviceToHost));
           for (int64_t i = 0; i < n; ++i) { const double x = bf2f(g[i]), e = fabs(x - (*rp[t])[i]); if (!(x == x)) ++bad; if (e > e3[t]) e3[t] = e; if (fabs((*rp[t])[i]) > m3[t]) m3[t] = fabs((*rp[t])[i]); }
         }
-        for (int i = 0; i < 3; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
+        for (int i = 0; i < 3; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
         CK(hipEventRecord(e0, nullptr));
-        for (int i = 0; i < iters; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr));
+        for (int i = 0; i < iters; ++i) GK(gmlm_attention_bwd(q, k, v, o, go, lse, len, c.b, c.h, c.l, c.l, c.d, st, st, st, scale, c.drop, seed, nullptr, dq, dk, dv, st, st, st, GMLM_BF16, nullptr, 0, ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
         CK(hipEventRecord(e1, nullptr)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
         printf("%-14s var=%d bwd %8.1f us  %7.1f TF/s padded(10/4 x fwd flops) (%.3f)  err dq %.4f/%.2f dk %.4f/%.2f dv %.4f/%.2f nan=%ld\n", c.tag, var, ms * 1e3,
@@ -221,10 +221,10 @@ int main(int argc, char** argv) {
     };
     auto bwd = [&]() {
       if (!by_class) { GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, nseq, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
-                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, cls_, ws, wsb, nullptr, nullptr, nullptr)); return; }
+                                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu, cls_, ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr)); return; }
       for (auto& c : cls)      // one call per capacity class: same tensors, cu_seqlens sub-range, the class's own max_len
         GK(gmlm_attention_bwd(qkv, qkv + hd, qkv + 2 * hd, o, go, lse, nullptr, c.second, h, T, T, d, 3 * hd, 3 * hd, 3 * hd, scale, 0.1f, 77, nullptr,
-                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr, nullptr, nullptr));
+                              dqkv, dqkv + hd, dqkv + 2 * hd, 3 * hd, 3 * hd, 3 * hd, GMLM_BF16, dcu + c.first, lens[c.first], ws, wsb, nullptr, nullptr, nullptr, nullptr, 0, nullptr));
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms;
