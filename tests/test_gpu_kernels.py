@@ -576,11 +576,13 @@ def test_attention_fused_short_sequence_backward(dev):
     bg = [torch.zeros(h * d, device=dev, requires_grad=True) for _ in range(3)]
     yg = attention_qkv(qkv_g, None, h, d ** -0.5, 0.0, False, cu.to(dev), 128, bias_masters=bg, groups=grp.to(dev))
     yg.backward(go)
-    assert torch.equal(yg, y)                                    # a row's scores, max and sum do not depend on the packing
+    # a row's scores and maximum do not depend on the packing; its keys fall into other 32-key blocks, so fp32 sums run in
+    # another order: at most an occasional bf16 ulp
+    assert float((yg.float() - y.float()).abs().max()) <= 2 ** -7 * float(y.float().abs().max())
     for j, name in enumerate("qkv"):
         a, r = qkv_g.grad[:, j * h * d:(j + 1) * h * d].float(), gr[:, j * h * d:(j + 1) * h * d]
         assert float((a - r).abs().max()) <= 2e-2 * float(r.abs().max()), name
-    assert torch.equal(qkv_g.grad, qkv.grad)
+    assert float((qkv_g.grad.float() - qkv.grad.float()).abs().max()) <= 2 ** -6 * float(qkv.grad.float().abs().max())
     dbg = torch.cat([t_.grad for t_ in bg])
     assert float((dbg.cpu() - db_ref.cpu()).abs().max()) <= 1e-2 * float(db_ref.abs().max()) + 1e-3
     # 14 sequences of one token + short ones: more sequences than a group may hold (13) must split, ids stay distinct
