@@ -89,9 +89,18 @@ def build_model(args, data, dev):
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     m = gmlm_amd.GraphTextLM(data["f_in"], args.hc, data["c"], dropout_rate=0.3, plm_encoder=enc,
                              plm_max_length=args.max_len, compute_dtype=cd,
-                             plm_gradient_checkpointing=args.plm_ckpt or args.workload == "arxiv",   # reference: main.py:217-218
-                             activation_checkpointing=args.workload == "arxiv")                      # reference: main.py:278-314
+                             plm_gradient_checkpointing=recompute_flags(args)[1],    # reference: ON (main.py:217-218)
+                             activation_checkpointing=recompute_flags(args)[0])      # reference: ON (main.py:278-314)
     return m.to(dev).train()
+
+
+def recompute_flags(args):
+    """(activation_checkpointing, plm_gradient_checkpointing).  The reference recomputes every RGCN block
+    (torch.utils.checkpoint, main.py:278-314) and every BertLayer (HF gradient checkpointing, main.py:217-219) in backward: same
+    results, more time, less memory.  The headline step runs WITHOUT recomputation (its activations fit easily) and says so in
+    ``config``; ``--reference-recompute`` / the ``reference_recompute`` leg run with both ON; arxiv always does."""
+    on = args.reference_recompute or args.workload == "arxiv"
+    return on, (on or args.plm_ckpt)
 
 
 def cpu_baseline(args, data, ids, am):
@@ -176,6 +185,18 @@ def cpu_baseline(args, data, ids, am):
                         f"{sample.numel()} of {idx.numel()} active nodes (median {t_plm:.1f}s) and scaled linearly"),
                 runs_s=dict(gnn_head=[round(r, 2) for r in runs], bert_sample=[round(r, 2) for r in pl]),
                 seconds_measured=round(time.time() - t_all, 1))
+
+
+def device_names(dev, world):
+    """What every rank runs on, gathered over the process group: lets the reader of the JSON line see that RCCL saw N ranks on
+    N different GPUs ("rank: name (cuda:i, pci bus id)")."""
+    props = torch.cuda.get_device_properties(dev)
+    mine = f"{props.name} (cuda:{dev.index}, uuid {str(getattr(props, 'uuid', ''))[-12:]})"
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    torch.distributed.all_gather_object(out, mine)
+    return out
 
 
 def _time_events(fn, iters, warm=2):
@@ -354,12 +375,12 @@ def s5_strong(dev, args, world, rank):
     GPUs, value = N_total / step time.  Every rank derives the same graph from the seeded generator on its own GPU and
     plans its partition from it (or reads its shard from --partition-dir); edge types use GLOBAL out-degrees."""
     import gmlm_amd
-    from gmlm_amd.dist import attach_partition
+    from gmlm_amd.dist import attach_partition, partition_file, write_partition_files
     from transformers import BertConfig, BertModel
     n, e, f_in = args.s5_nodes, args.s5_edges, 768
-    g = torch.Generator(device=dev).manual_seed(1005)
-    ei = None
-    if args.partition_dir is None or world == 1:
+
+    def make_graph():
+        g = torch.Generator(device=dev).manual_seed(1005)
         w = (torch.arange(n, device=dev, dtype=torch.float32) + 1.0).pow(-1.0 / 1.2)
         perm = torch.randperm(n, device=dev, generator=g)
         # multinomial with replacement caps the category count at 2^24: sample through the CDF instead
@@ -367,19 +388,54 @@ def s5_strong(dev, args, world, rank):
         cdf /= cdf[-1].clone()
         src = perm[torch.searchsorted(cdf, torch.rand(e, device=dev, generator=g, dtype=torch.float64)).clamp_(max=n - 1)]
         dst = perm[torch.searchsorted(cdf, torch.rand(e, device=dev, generator=g, dtype=torch.float64)).clamp_(max=n - 1)]
-        ei = torch.stack([src, dst])
-        del w, perm, cdf, src, dst
+        return torch.stack([src, dst])
+
+    ei, pdir, t_part = None, args.partition_dir, 0.0
+    if world == 1:
+        ei = make_graph()
+    elif pdir is None or not os.path.exists(partition_file(pdir, rank, world)):
+        # Default for N > 1: the graph is partitioned ONCE - rank 0 builds it, plans every rank's shard and writes
+        # part-RRRRR-of-WWWWW.npz - and each rank then reads only its own shard (1/N of the edges, its halo and send lists)
+        # instead of holding the 100M-edge list and running the planning (degree histogram, unique, sort) N times over.
+        import tempfile
+        pdir = pdir or os.path.join(tempfile.gettempdir(), f"gmlm_s5_parts_n{n}_e{e}_w{world}")
+        t0 = time.perf_counter()
+        if rank == 0 and not all(os.path.exists(partition_file(pdir, r, world)) for r in range(world)):
+            full = make_graph()
+            write_partition_files(full, n, world, pdir)
+            del full
+            torch.cuda.empty_cache()
+        torch.distributed.barrier()
+        t_part = time.perf_counter() - t0
     enc = BertModel(BertConfig(vocab_size=64, hidden_size=768, num_hidden_layers=1, num_attention_heads=12,
                                intermediate_size=64, max_position_embeddings=16))       # not executed: P = 768 only
     torch.manual_seed(0)
     m = gmlm_amd.GraphTextLM(f_in, args.s5_hc, 16, dropout_rate=0.3, plm_encoder=enc, compute_dtype=torch.bfloat16,
                              activation_checkpointing=True).to(dev).train()
     if world > 1:
-        part = attach_partition(m, ei, n, dev, partition_dir=args.partition_dir)
+        part = attach_partition(m, None, n, dev, partition_dir=pdir)
         lo, hi = part.plan.lo, part.plan.hi
         halo = part.plan.n_halo
     else:
         part, lo, hi, halo = None, 0, n, 0
+    # pre-flight: this rank's peak is the widest block's recompute + backward.  Its input buffer holds owned + halo rows at
+    # 4 * hc columns and exists together with its gradient; next to it the aggregation output H [n_local, R_a * 4 hc], its
+    # gradient, the block output [n_local, 8 hc] (+ gradient, + GraphNorm's bf16 input) and the fp32 fusion accumulator.
+    hc = args.s5_hc
+    rows_in, rows_out = (hi - lo) + halo, hi - lo
+    est = (2 * rows_in * 4 * hc * 2 + 2 * rows_out * 4 * 4 * hc * 2 + 3 * rows_out * 8 * hc * 2 + rows_out * 768 * 4 * 3
+           + rows_out * f_in * 2 * 2 + 30 * 4 * hc * 8 * hc * 4 * 3)
+    total_mem = torch.cuda.get_device_properties(dev).total_memory
+    fits = torch.tensor([1.0 if est < 0.9 * total_mem else 0.0])
+    if world > 1:
+        part.all_reduce_min(fits)                                   # the same decision on every rank, taken BEFORE the first collective of a step
+    if float(fits) < 0.5:
+        return {"metric": "nodes/sec fwd+bwd (get_graph_embeddings, 10M-node power-law graph)", "value": None, "unit": "nodes/s",
+                "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"s5 hidden_channels={hc}: NOT RUN, pre-flight memory estimate {est / 1e9:.0f} GB per rank "
+                                       f"(rows {rows_out} + halo {halo}) exceeds 90 % of {total_mem / 1e9:.0f} GB on some rank; use more GPUs or a smaller --s5-hc",
+                           "world": world}}
     gx = torch.Generator(device=dev).manual_seed(77)                  # same stream on every rank: row i is the same wherever it lives
     x = torch.empty(hi - lo, f_in, device=dev, dtype=torch.bfloat16)
     chunk = 1 << 20
@@ -392,9 +448,6 @@ def s5_strong(dev, args, world, rank):
     del blk
     mask = (torch.rand(n, device=dev, generator=gx) < 0.3)[lo:hi]
     r_a = m.graph(ei, n).r_active if part is None else part.csr.r_active
-    if part is not None:
-        ei = None                                                      # the partition's CSR replaces the edge list
-        torch.cuda.empty_cache()
 
     def step():
         m.zero_grad(set_to_none=True)
@@ -431,7 +484,10 @@ def s5_strong(dev, args, world, rank):
         "config": {"workload": f"s5: Chung-Lu power-law graph N={n} E={e} F_in={f_in}, hidden_channels={args.s5_hc}, P=768, R_a={r_a}, "
                                f"get_graph_embeddings forward+backward with activation checkpointing and reference dropout",
                    "global_nodes": n, "parallelism": f"1-D node partition x{world}" if world > 1 else "single GPU",
-                   "rows_per_rank": hi - lo, "halo_rows_rank0": halo,
+                   "rows_per_rank": hi - lo, "halo_rows_rank0": halo, "activation_checkpointing": True,
+                   "partition": (f"shard files ({pdir}): rank 0 plans and writes once ({t_part:.1f} s incl. barrier), every rank loads its own" if world > 1 else None),
+                   "preflight_mem_estimate_GB": round(est / 1e9, 1),
+                   "world": world, "backend": (torch.distributed.get_backend() if world > 1 else None), "devices": device_names(dev, world),
                    "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1)}}
 
 
@@ -443,9 +499,11 @@ def main():
     ap.add_argument("--workload", default="squirrel", choices=list(WORKLOADS) + ["s5"])
     ap.add_argument("--s5-nodes", type=int, default=10_000_000)
     ap.add_argument("--s5-edges", type=int, default=100_000_000)
-    ap.add_argument("--s5-hc", type=int, default=96, help="hidden_channels of the s5 GNN run (F_in = P = 768; 96 keeps the 10M-node activations on ONE GPU for the N=1 point)")
+    ap.add_argument("--s5-hc", type=int, default=96, help="hidden_channels of the s5 GNN run (F_in = P = 768; 96 keeps the 10M-node activations on ONE GPU for the N=1 point; "
+                    "768 = BASELINE's h is meant for >= 8 GPUs: a pre-flight per-rank memory estimate decides collectively whether the step is run)")
     ap.add_argument("--partition-dir", default=None, help="s5: read this rank's shard (gmlm_amd.dist.write_partition_files) instead of planning from the edge list")
     ap.add_argument("--plm-ckpt", action="store_true", help="HF-style gradient checkpointing of the text encoder (reference: main.py:217-218)")
+    ap.add_argument("--reference-recompute", action="store_true", help="activation checkpointing of the RGCN blocks AND of the BertLayers, as the reference runs (main.py:217-219, 278-314)")
     ap.add_argument("--no-fp32-leg", action="store_true")
     ap.add_argument("--no-gemm-tuning", action="store_true", help="library default GEMM algorithms instead of the looked-up picks (gmlm_amd/tuning.py)")
     ap.add_argument("--gemm-tune", default=None, metavar="CSV", help="time the library's GEMM candidates for every shape of this run and write the picks to CSV (offline step)")
@@ -530,6 +588,7 @@ def main():
         lo, hi = part.plan.lo, part.plan.hi
     else:
         part, lo, hi = None, 0, data["n"]
+    devices = device_names(dev, world)
     x = data["x"][lo:hi].to(dev)
     y = data["y"][lo:hi].to(dev)
     active = data["active"][lo:hi].to(dev)
@@ -591,6 +650,10 @@ def main():
                                f"hidden_channels={args.hc}, BERT geometry {args.plm_hidden}x{args.plm_layers}, "
                                f"{n_active_total} active text nodes, 16..{args.max_len} tokens, plm_batch_size={args.plm_batch}",
                    "global_nodes": data["n"], "parallelism": f"1-D node partition x{world}" if distributed else "single GPU",
+                   "activation_checkpointing": bool(recompute_flags(args)[0]), "plm_gradient_checkpointing": bool(recompute_flags(args)[1]),
+                   "recompute_note": "the reference recomputes RGCN blocks and BertLayers in backward (main.py:217-219, 278-314); this line runs "
+                                     + ("WITH both, like the reference" if all(recompute_flags(args)) else "WITHOUT recomputation (same results; the reference-mode time is in reference_recompute)"),
+                   "world": world, "backend": (torch.distributed.get_backend() if distributed else None), "devices": devices,
                    "hip_graph": bool(args.hip_graph),
                    "gemm_algorithms": ("library picks from gmlm_amd/tunable/gfx950.csv (TunableOp lookup)" if gemm_tuning and not args.gemm_tune
                                        else "tuned in this run" if gemm_tuning else "library default heuristic"),
@@ -619,6 +682,11 @@ def main():
             sp_in.update({"regime": "cache-resident X (8-32 MB): reported against the L2 / Infinity-Cache gather rate, not HBM",
                           "bound": "l2/mall", "peak_GBps": 17000.0, "frac_l2_gather_rate": round(sp_in["algorithmic_GBps"] / 17000.0, 4),
                           "pmc_hbm_side_bytes_per_launch": _pmc_traffic("spmm_fwd_in_step")})
+        sp_bw = kern.get("spmm_bwd")
+        if sp_bw is not None and world == 1:
+            sp_bw.pop("frac_hbm_peak", None)
+            sp_bw.update({"regime": "cache-resident dH (8-32 MB): reported against the L2 / Infinity-Cache gather rate, not HBM",
+                          "bound": "l2/mall", "peak_GBps": 17000.0, "frac_l2_gather_rate": round(sp_bw["algorithmic_GBps"] / 17000.0, 4)})
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_micro and args.workload == "squirrel":
         del model
@@ -674,6 +742,32 @@ def main():
                        "note": "same workload, fp32 operands (exact-f32 MFMA attention, fp32 GEMMs)"}
         del m32
         torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and args.workload == "squirrel" and not args.reference_recompute:
+        # the same step the way the reference runs it: every RGCN block and every BertLayer recomputed in backward
+        argsr = argparse.Namespace(**{**vars(args), "reference_recompute": True})
+        mr = build_model(argsr, data, dev)
+
+        def step_r():
+            mr.zero_grad(set_to_none=True)
+            lg = mr(mr.soft_mask_input(x, active, 0.7), ei, tokens, active, plm_batch_size=args.plm_batch)
+            idx = mr.active_index
+            (F.cross_entropy(lg.index_select(0, idx), y.index_select(0, idx), label_smoothing=0.2, reduction="sum") / n_active_total).backward()
+
+        torch.cuda.reset_peak_memory_stats()
+        step_r()
+        step_r()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            step_r()
+        torch.cuda.synchronize()
+        dr = (time.perf_counter() - t0) / 3
+        out["reference_recompute"] = {"ms_per_step": round(dr * 1e3, 2), "value": round(data["n"] / dr, 1), "unit": "nodes/s", "steps": 3,
+                                      "activation_checkpointing": True, "plm_gradient_checkpointing": True,
+                                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2),
+                                      "note": "same workload with the reference's recomputation (main.py:217-219, 278-314): identical results, forward of every block runs twice"}
+        del mr
+        torch.cuda.empty_cache()
     if rank == 0 and world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and args.workload == "squirrel":
         # the headline graph's uniform edges put every edge in degree bucket 3 (R_a = 1); real Squirrel is heavy-tailed.  Same
         # sizes with Chung-Lu power-law out-degrees (alpha = 2.2): all four degree buckets occur, the relation-segmented
@@ -710,9 +804,19 @@ def main():
         except Exception as exc:  # the baseline is a reported number, never a reason to lose the bench line
             out["cpu_baseline"] = {"value": None, "unit": "nodes/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {exc!r}"}
     if rank == 0:
+        out["child_processes_at_exit"] = child_processes()
         print(json.dumps(out))
     if distributed:
         torch.distributed.destroy_process_group()
+
+
+def child_processes():
+    """Names of the processes this one has started and not reaped (the bench starts none: [] expected)."""
+    try:
+        import psutil
+        return [c.name() for c in psutil.Process().children(recursive=True)]
+    except Exception as exc:          # psutil is part of the image; never a reason to lose the line
+        return [f"unknown: {exc!r}"]
 
 
 if __name__ == "__main__":
