@@ -217,8 +217,8 @@ __device__ __forceinline__ void store_t(T* rowptr /* + db*32 applied */, const f
       *reinterpret_cast<float4*>(p) = make_float4(acc[4 * g4] * mul, acc[4 * g4 + 1] * mul, acc[4 * g4 + 2] * mul, acc[4 * g4 + 3] * mul);
     } else {
       uint2 w;
-      w.x = (uint32_t)f32_to_bf16(acc[4 * g4] * mul) | ((uint32_t)f32_to_bf16(acc[4 * g4 + 1] * mul) << 16);
-      w.y = (uint32_t)f32_to_bf16(acc[4 * g4 + 2] * mul) | ((uint32_t)f32_to_bf16(acc[4 * g4 + 3] * mul) << 16);
+      w.x = pack_bf16x2(acc[4 * g4] * mul, acc[4 * g4 + 1] * mul);
+      w.y = pack_bf16x2(acc[4 * g4 + 2] * mul, acc[4 * g4 + 3] * mul);
       *reinterpret_cast<uint2*>(p) = w;
     }
   }
@@ -229,15 +229,15 @@ __device__ __forceinline__ void store_t(T* rowptr /* + db*32 applied */, const f
 __device__ __forceinline__ void store_t_lo(bf16_t* rowptr, const f32x16& acc, float mul, int h) {
 #pragma unroll
   for (int g4 = 0; g4 < 4; ++g4) {
-    uint32_t lo[4];
+    float x[4], d[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float x = acc[4 * g4 + j] * mul;
-      lo[j] = (uint32_t)f32_to_bf16(x - bf16_to_f32(f32_to_bf16(x)));
-    }
+    for (int j = 0; j < 4; ++j) x[j] = acc[4 * g4 + j] * mul;
+    const uint32_t h0 = pack_bf16x2(x[0], x[1]), h1 = pack_bf16x2(x[2], x[3]);
+    d[0] = x[0] - __uint_as_float(h0 << 16); d[1] = x[1] - __uint_as_float(h0 & 0xffff0000u);
+    d[2] = x[2] - __uint_as_float(h1 << 16); d[3] = x[3] - __uint_as_float(h1 & 0xffff0000u);
     uint2 w;
-    w.x = lo[0] | (lo[1] << 16);
-    w.y = lo[2] | (lo[3] << 16);
+    w.x = pack_bf16x2(d[0], d[1]);
+    w.y = pack_bf16x2(d[2], d[3]);
     *reinterpret_cast<uint2*>(rowptr + 8 * g4 + 4 * h) = w;
   }
 }

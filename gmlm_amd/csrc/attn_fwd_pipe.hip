@@ -6,9 +6,10 @@
 // keys in the accumulator registers; P feeds O^T += V^T P^T from registers; V^T through ds_read_b64_tr_b16.
 // What is different:
 //  * schedule.  The unit of work is 32 keys (one 32x32 score block).  At step u a wave issues, in ONE basic block,
-//        check(u):            wave vote "does block u exceed the reference max by more than 2^kDefer" (8 v_max3 + vote)
 //        QK(u+1) and PV(u-1): 1 + D/16 + 2*D/32 MFMAs
 //        SM(u):               exp2 / row sum / bf16 packing of block u -- one probability pair per MFMA gap
+//        check(u):            wave vote on the block's ROW SUM (already there: no extra arithmetic): "did some probability of
+//                             block u leave the deferral window", see `settle` below
 //    hand-interleaved (one MFMA per gap, fenced by sched_barrier(0)), so the matrix pipe works on the neighbouring
 //    blocks while the VALU does the softmax of this one: the two pipes overlap INSIDE a wave.
 //  * softmax arithmetic per score = v_exp + v_add (+ half a v_cvt_pk, half a v_max3).  Q is pre-multiplied by
@@ -264,36 +265,54 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
       o[j % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pk[j / DB], o[j % DB], 0, 0, 0);
     }
   };
-  // block u against the reference max: the common case is a wave vote on "no score exceeds m by 2^kDefer" (each
-  // half-wave looks at its own 16 keys: no exchange needed for a wave-uniform decision).  Otherwise (first block,
-  // or a real jump) the reference moves to the bf16-rounded row max: s' -= delta, l *= alpha now; O *= alpha after
-  // the pending PV(u-1) has been accumulated, so that everything summed so far is at the old scale exactly once
-  // (guide T13 hazard).  Returns alpha (1 when nothing moved).
-  auto check = [&](f32x16& sc, int u, bool& rare) {
-    const float g = max16(sc);                          // masked keys sit at about -1.3e30 (see ones_for)
-    rare = u == 0 || !__all(g <= kDefer);
-    float alpha = 1.f;
-    if (rare) {
-      const float gr = xhalf_max(g);                    // finite: the first key of every block is valid
-      float m_new = bf16_round(m + gr);
-      if (u != 0) m_new = fmaxf(m, m_new);              // only ever raised after the first block
-      const float delta = m_new - m;
-      alpha = u == 0 ? 1.f : fast_exp2(-delta);         // first block: O = l = 0, nothing to scale (and -delta may be huge)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sc[i] -= delta;
-      l *= alpha;
-      m = m_new;
-      qx[0] = h == 0 ? (__bf16)(-m_new) : (__bf16)0.f;
-    }
-    return alpha;
-  };
+  // Block u against the reference max m.  The exponentials of block u are formed against the CURRENT reference without looking
+  // at the scores first; the lane's partial row sum of the block then tells whether that was fine: 16 probabilities that sum to
+  // <= 2^8 are each <= 2^8 (bf16 P keeps its 8 mantissa bits at any scale, the f32 sums have room), and a probability beyond
+  // that - or an overflow to +inf for a score that jumped by more than 2^7 - makes the sum exceed the bound (NaN-safe compare).
+  // That replaces the per-block max scan of the scores (8 v_max3 + canonicalisation: 13 of ~70 VALU per block).  When the vote
+  // fails (first block, or a real jump) the block is REDONE out of line: reference <- bf16(row max), exponentials, packing and
+  // row sum recomputed, the scores of block u+1 (already produced against the old reference by this step's QK) shifted, l and -
+  // after the pending PV(u-1), which this step has finished - O rescaled: everything summed so far is at the old scale
+  // exactly once (guide T13 hazard).  The probabilities of block u are consumed by the NEXT step's PV, so nothing stale is used.
+  constexpr float kSumDefer = 256.f;
   auto scale_o = [&](float alpha) {
 #pragma unroll
     for (int d = 0; d < DB; ++d)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[d][i] *= alpha;
   };
-
+  auto settle = [&](f32x16& sc, bf16x8 (&pc)[2], f32x16& sn, int u) {
+    const float gr = xhalf_max(max16(sc));               // finite: the first key of every block is valid
+    float m_new = bf16_round(m + gr);
+    if (u != 0) m_new = fmaxf(m, m_new);                 // only ever raised after the first block
+    const float delta = m_new - m;
+    if (u != 0) {                                        // first block: O = l = 0, nothing to scale (and -delta may be huge)
+      const float alpha = fast_exp2(-delta);
+      scale_o(alpha);
+      l *= alpha;
+    }
+    m = m_new;
+    qx[0] = h == 0 ? (__bf16)(-m_new) : (__bf16)0.f;
+    __builtin_amdgcn_sched_barrier(0);                   // keep the register pressure of this rare path sequential: O first, then the block
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+      const float e0 = fast_exp2(sc[i] - delta), e1 = fast_exp2(sc[i + 1] - delta);
+      sn[i] -= delta; sn[i + 1] -= delta;
+      r0 += e0; r1 += e1;
+      float d0 = e0, d1 = e1;
+      if (DROP) {
+        float m0, m1;
+        drop_pair_q(dq_u + (uint32_t)(16 * u + (acc_row(i, 0) >> 1)) * kDropC2, q_odd, p.drop_thresh, p.keep_scale, m0, m1);
+        d0 = e0 * m0;
+        d1 = e1 * m1;
+      }
+      pc[i >> 3][i & 7] = (__bf16)d0;
+      pc[i >> 3][(i & 7) + 1] = (__bf16)d1;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l += r0 + r1;
+  };
   // ---- steady-state step: PV(u-1) and QK(u+1) on the matrix pipe under the softmax of block u ---------------
   //  sc: scores of block u (log2 domain, reference max subtracted)   pc: packed probabilities of block u (output)
   //  sn: receives the scores of block u+1                              pp: packed probabilities of block u-1
@@ -308,8 +327,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     for (int s = 0; s < NQ; ++s) ka[s] = kfrag(koffs, s);
     bf16x4 vlo[NP], vhi[NP];
     constexpr int LA = 3;                               // PV operand reads run LA gaps ahead of their MFMA
-    bool rare;
-    const float alpha = check(sc, u, rare);
     // hand-placed: one MFMA per gap, the operand reads of a later MFMA, one probability pair;
     // sched_barrier(0) keeps every gap's instructions inside the gap
     float rs0 = 0.f, rs1 = 0.f, pe0 = 0.f, pe1 = 0.f;
@@ -342,8 +359,9 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
     // pin the probabilities inside this basic block (their consumers are in later blocks: without a use here the
     // compiler sinks the whole softmax below the MFMAs, past the branch that follows)
     asm volatile("" : "+v"(pc[0]), "+v"(pc[1]), "+v"(rs0), "+v"(rs1), "+v"(pe0), "+v"(pe1));
-    l += (rs0 + pe0) + (rs1 + pe1);
-    if (rare) scale_o(alpha);
+    const float rs = (rs0 + pe0) + (rs1 + pe1);
+    if (u == 0 || !__all(rs <= kSumDefer)) settle(sc, pc, sn, u);      // rare, out of line
+    else l += rs;
   };
 
   f32x16 sa, sb;
@@ -453,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_pipe_kernel(AttnParams p) {
   STAMP(t_loop_end);
   if (q_ok) {
     l = xhalf_sum(l);
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+    const float inv = l > 0.f ? __builtin_amdgcn_rcpf(l) : 0.f;      // 1 ulp: the output is rounded to bf16 right after
     T* og = static_cast<T*>(p.o_w) + ((qbase + q_row) * p.h + hd) * D;
 #pragma unroll
     for (int d = 0; d < DB; ++d) store_t<T>(og + d * 32, o[d], inv, h);

@@ -76,6 +76,15 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return *reinterpret_cast<bf16_t*>(&b);
 }
 
+// two f32 -> one dword of two bf16 (lo in bits 0-15): ONE v_cvt_pk_bf16_f32 (round to nearest even, NaN stays NaN) instead of two
+// single conversions + shift + or
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
 template <typename T> struct Store;
 template <> struct Store<float> {
   static constexpr int kVec = 4;  // elements per 16 bytes
@@ -110,7 +119,7 @@ template <> struct Store<bf16_t> {
   __device__ static __forceinline__ void stv(bf16_t* p, const float (&o)[8]) {
     uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f32_to_bf16(o[2 * i]) | ((uint32_t)f32_to_bf16(o[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(o[2 * i], o[2 * i + 1]);
     *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
   }
 };

@@ -328,8 +328,8 @@ __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const float* __restr
         *reinterpret_cast<float4*>(out + r * p + c) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
         uint2 v;
-        v.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
-        v.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        v.x = pack_bf16x2(o[0], o[1]);
+        v.y = pack_bf16x2(o[2], o[3]);
         *reinterpret_cast<uint2*>(out + r * p + c) = v;
       }
     }
