@@ -20,6 +20,7 @@
 #include "attn_common.hpp"
 #include "colreduce.hpp"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace gmlm {
@@ -593,6 +594,7 @@ namespace gmlm {
 int attn_fwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t bh, hipStream_t st);
 int attn_short_fwd_launch(const AttnParams& p, int64_t rows, int64_t items, hipStream_t st);
 int attn_short_bwd_launch(const AttnParams& p, int64_t rows, int64_t items, float* dbias, hipStream_t st);
+int attn_bwd_pipe_launch(const AttnParams& p, int d, int nw, int64_t rows_q, int64_t rows_k, int64_t bh, hipStream_t st);
 }
 
 static inline int pick_waves(int64_t rows, int64_t bh) {
@@ -722,6 +724,11 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, nullptr, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
+  if (dtype == GMLM_BF16 && d == 96 && !getenv("GMLM_BWD_REGSTAGE")) {
+    // CrossAttention geometry: LDS-DMA staged kernels (attn_bwd_pipe.hip): no staging registers (the register-staged 2- / 4-wave
+    // variants spill 44-88 bytes per lane at d = 96), 4-wave workgroups unless the grid fills the chip twice with 8
+    return attn_bwd_pipe_launch(p, (int)d, pick_waves(rows_q, b * h) == 8 ? 8 : 4, rows_q, rows_k, b * h, st);
+  }
   if (pick_waves(rows_q, b * h) == 8) {
     dim3 gq((unsigned)cdiv(rows_q, 256), (unsigned)(b * h));
     GMLM_ATTN_DISPATCH(attn_bwd_dq_kernel, 8, gq, st, p);
@@ -756,7 +763,7 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     }
   } else {
     dim3 gk((unsigned)cdiv(rows_k, 64), (unsigned)(b * h));
-    if (dtype == GMLM_BF16 && rows_q > 128) {      // 64-row tiles here too: -11 % at N = 5,201
+    if (dtype == GMLM_BF16 && rows_q > 128 && !getenv("GMLM_DKV_QT32")) {      // 64-row tiles here too: -11 % at N = 5,201
       if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 2, false, 64><<<gk, 128, 0, st>>>(p); }
       else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 2, false, 64><<<gk, 128, 0, st>>>(p); }
     } else {
