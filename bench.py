@@ -515,15 +515,17 @@ def main():
     ap.add_argument("--no-ring", action="store_true")
     ap.add_argument("--cpu-repeats", type=int, default=3)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--hc", type=int, default=768)
-    ap.add_argument("--plm-hidden", type=int, default=768)
-    ap.add_argument("--plm-layers", type=int, default=12)
+    ap.add_argument("--hc", type=int, default=None, help="hidden_channels (default per workload: 768; chameleon 256, cornell 512)")
+    ap.add_argument("--plm-hidden", type=int, default=None, help="text encoder width (default 768 = BERT-base; chameleon 256 = BERT-mini)")
+    ap.add_argument("--plm-layers", type=int, default=None, help="text encoder depth (default 12; chameleon 4)")
     ap.add_argument("--vocab", type=int, default=30522)
     ap.add_argument("--max-len", type=int, default=128)
     ap.add_argument("--plm-batch", type=int, default=4096, help="text micro-batch (nodes); default = all active nodes in ONE packed batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-plm-sample", type=int, default=64)
     ap.add_argument("--cpu-hc", type=int, default=768)
+    ap.add_argument("--no-encoder-graph", action="store_true", help="with hipGraphs: leave the text encoder eager (GNN + head regions only)")
+    ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile the timed steps (host side) and write the top entries to FILE")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the kernel micro-benchmarks (rank 0, N=1 only)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo = 1-GPU rehearsal of the N>1 path)")
@@ -562,6 +564,12 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
+    # per-workload geometry (BASELINE.json configs): Chameleon-size is quoted with BERT-mini (256 x 4, 4 heads) and hc 256,
+    # Cornell-size with BERT-base and hc 512, everything else with BERT-base and hc 768
+    preset = {"chameleon": (256, 256, 4), "cornell": (512, 768, 12)}.get(args.workload, (768, 768, 12))
+    args.hc = preset[0] if args.hc is None else args.hc
+    args.plm_hidden = preset[1] if args.plm_hidden is None else args.plm_hidden
+    args.plm_layers = preset[2] if args.plm_layers is None else args.plm_layers
     if args.gnn_large:
         print(json.dumps({"gnn_large": gnn_large(dev, args)}))
         return
@@ -600,7 +608,7 @@ def main():
     if args.hip_graph:
         if distributed:
             raise SystemExit("--hip-graph is single-GPU")
-        model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei)
+        model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei, encoder=not args.no_encoder_graph)
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -629,11 +637,24 @@ def main():
     timer = None if args.no_kernel_timers else ops.KernelTimer()
     ops.TIMER = timer
     fence()
+    prof = None
+    if args.host_profile:                                # where a launch-bound step spends its HOST time (not a bench number)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(45)
+        with open(args.host_profile, "w") as f:
+            f.write(f"{args.steps} steps, {dt / args.steps * 1e3:.3f} ms/step under cProfile\n" + buf.getvalue())
     ops.TIMER = None
     if distributed:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -20,7 +20,6 @@
 #include "attn_common.hpp"
 #include "colreduce.hpp"
 
-#include <stdlib.h>
 #include <type_traits>
 
 namespace gmlm {
@@ -724,9 +723,10 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
       attn_delta_kernel<float><<<(unsigned)cdiv(threads, 256), 256, 0, st>>>((const float*)out, nullptr, (const float*)dout, rows, (int)d, lq, h, p.delta);
   }
   GMLM_LAUNCH_CHECK();
-  if (dtype == GMLM_BF16 && d == 96 && !getenv("GMLM_BWD_REGSTAGE")) {
+  if (dtype == GMLM_BF16 && d == 96) {
     // CrossAttention geometry: LDS-DMA staged kernels (attn_bwd_pipe.hip): no staging registers (the register-staged 2- / 4-wave
-    // variants spill 44-88 bytes per lane at d = 96), 4-wave workgroups unless the grid fills the chip twice with 8
+    // variants spill 44-88 bytes per lane at d = 96), 4-wave workgroups unless the grid fills the chip twice with 8.
+    // bf16 below this point is therefore d = 64
     return attn_bwd_pipe_launch(p, (int)d, pick_waves(rows_q, b * h) == 8 ? 8 : 4, rows_q, rows_k, b * h, st);
   }
   if (pick_waves(rows_q, b * h) == 8) {
@@ -743,8 +743,7 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
   if (pick_waves(rows_k, b * h) == 8 && !(dtype == GMLM_F32 && d == 96)) {   // f32 d=96 at 512 threads would spill
     dim3 gk((unsigned)cdiv(rows_k, 256), (unsigned)(b * h));
     if (dtype == GMLM_BF16) {   // long sequences: 64 query rows per barrier (two 32-row blocks), double-buffered
-      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 8, true, 64><<<gk, 512, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 8, false, 64><<<gk, 512, 0, st>>>(p); }
-      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 8, true, 64><<<gk, 512, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 8, false, 64><<<gk, 512, 0, st>>>(p); }
+      { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 8, true, 64><<<gk, 512, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 8, false, 64><<<gk, 512, 0, st>>>(p); }
     } else {
       GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 8, gk, st, p);
     }
@@ -752,20 +751,17 @@ extern "C" int gmlm_attention_bwd(const void* q, const void* k, const void* v, c
     dim3 gk((unsigned)cdiv(rows_k, 128), (unsigned)(b * h));
     if (dtype == GMLM_BF16 && rows_q <= 128) {
       // short sequences (the reference tokenises to <= 128 tokens): all query rows staged behind one barrier
-      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 128><<<gk, 256, 0, st>>>(p); }
-      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 4, false, 128><<<gk, 256, 0, st>>>(p); }
+      { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 128><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 128><<<gk, 256, 0, st>>>(p); }
     } else if (dtype == GMLM_BF16) {
       // 64 query rows per barrier (two 32-row blocks), double-buffered: -8 % at L = 512 against 32-row tiles
-      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 64><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 64><<<gk, 256, 0, st>>>(p); }
-      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 4, true, 64><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 4, false, 64><<<gk, 256, 0, st>>>(p); }
+      { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 4, true, 64><<<gk, 256, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 4, false, 64><<<gk, 256, 0, st>>>(p); }
     } else {
       GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 4, gk, st, p);
     }
   } else {
     dim3 gk((unsigned)cdiv(rows_k, 64), (unsigned)(b * h));
-    if (dtype == GMLM_BF16 && rows_q > 128 && !getenv("GMLM_DKV_QT32")) {      // 64-row tiles here too: -11 % at N = 5,201
-      if (d == 64) { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 2, false, 64><<<gk, 128, 0, st>>>(p); }
-      else { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 96, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 96, 2, false, 64><<<gk, 128, 0, st>>>(p); }
+    if (dtype == GMLM_BF16 && rows_q > 128) {      // 64-row tiles here too: -11 % at N = 5,201
+      { if (p.drop_thresh) attn_bwd_dkv_kernel<bf16_t, 64, 2, true, 64><<<gk, 128, 0, st>>>(p); else attn_bwd_dkv_kernel<bf16_t, 64, 2, false, 64><<<gk, 128, 0, st>>>(p); }
     } else {
       GMLM_ATTN_DISPATCH(attn_bwd_dkv_kernel, 2, gk, st, p);
     }

@@ -5,8 +5,14 @@ the same head kernels (2 x CrossAttention + fusion MLP + classifier: main.py:360
 Cornell / Chameleon-size graphs those are a few hundred launches of 3-30 us each and the step is bound by the host's launch
 rate, not by the GPU.  ``capture(model, x_sample, edge_index)`` records both regions (forward AND backward) once with
 ``torch.cuda.make_graphed_callables`` — the ctypes launches of libgmlm_hip go to the capturing stream like any other kernel —
-and ``model.forward`` replays them.  The text encoder in between stays eager: its packed token count changes with the
-active-node mask of every step.
+and ``model.forward`` replays them.
+
+The text encoder in between sees a different active set every step (main.py:532-534 draws the mask per epoch), so its packed
+token count moves.  It is recorded per SIZE BUCKET instead: ``model.bucketed_layout`` pads the packed batch with dummy [PAD]
+sequences to a multiple of 64 sequences / 2,048 tokens / 32 attention work items, every index the pass needs is computed on
+the device from three small per-step tables (sequence lengths, node of each sequence, cumulative lengths), and
+``GraphedStep.encoder`` keeps one hipGraph (forward + backward, weight casts included) per bucket in a small LRU.  Replaying
+copies the step's tables into the graph's static inputs.  Batches that need more than one micro-batch run eagerly.
 
 Dropout under replay: a captured kernel argument is a constant, so the host seeds drawn at capture time would repeat the same
 masks forever.  Every dropout kernel therefore takes ``(seed, seed_dev)`` and uses ``seed + *seed_dev`` (include/gmlm_hip.h);
@@ -61,7 +67,8 @@ class GraphedStep:
     """Holds the two captured regions of one (model, graph) pair.  ``gnn(xm)`` -> fp32 [N, P] graph embeddings,
     ``head(gnn_embeds, plm_embeds)`` -> logits; both are autograd-aware graph replays."""
 
-    def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None):
+    def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
+                 encoder: bool = True):
         if model.dist is not None:
             raise ValueError("hipGraph capture is single-GPU: collectives of the node partition are not captured")
         if not model.training:
@@ -69,6 +76,9 @@ class GraphedStep:
         dev = xm_sample.device
         self.key = (tuple(xm_sample.shape), xm_sample.dtype, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
         self.counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.encoder_enabled = bool(encoder)
+        self.encoder_buckets = 4                         # recordings kept (LRU)
+        self._encoders = {}                              # bucket key -> (token set, graphed region)
         model.graph(edge_index, xm_sample.size(0), edge_type).active_index    # CSR build (sort, host syncs) happens before capture
         p_dim = model.plm_encoder.config.hidden_size
         n = xm_sample.size(0)
@@ -88,15 +98,35 @@ class GraphedStep:
         regions = (_Region(gnn_fn, gnn_params, self.counter, True), _Region(head_fn, head_params, self.counter, False))
         self.gnn, self.head = torch.cuda.make_graphed_callables(regions, ((xs,), (gs, ts)), num_warmup_iters=2)
 
+    def encoder(self, model, key, tokens, tables):
+        """Replay (recording it first if needed) the encoder pass of bucket ``key`` over this step's index tables."""
+        hit = self._encoders.get(key)
+        if hit is None or hit[0] is not tokens:
+            def enc_fn(*t):
+                return model.encode_packed_static(tokens, key, *t)
+
+            samples = tuple(t.clone() for t in tables)
+            used = _touched_params(model, lambda: enc_fn(*samples).sum().backward())
+            region = torch.cuda.make_graphed_callables(_Region(enc_fn, used, self.counter, False), samples, num_warmup_iters=2)
+            while len(self._encoders) >= self.encoder_buckets:
+                self._encoders.pop(next(iter(self._encoders)))              # oldest recording: its graph and activations are freed
+            hit = (tokens, region)
+        else:
+            self._encoders.pop(key)
+        self._encoders[key] = hit                                           # most recently used last
+        return hit[1](*tables)
+
     def matches(self, xm: torch.Tensor, edge_index: torch.Tensor) -> bool:
         return self.key == (tuple(xm.shape), xm.dtype, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
 
 
-def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None) -> GraphedStep:
+def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
+            encoder: bool = True) -> GraphedStep:
     """Record the GNN and head regions for this (soft-masked input shape, graph) and attach them to ``model``:
     ``model.forward`` replays them whenever it is called in training mode with an input of the same shape / dtype and the
-    same ``edge_index`` tensor; any other call runs eagerly.  ``model.release_hip_graphs()`` drops the recording."""
+    same ``edge_index`` tensor; any other call runs eagerly.  ``encoder``: also record the text encoder, per size bucket, the
+    first time a step needs that bucket.  ``model.release_hip_graphs()`` drops the recordings."""
     model._graphed = None
-    g = GraphedStep(model, xm_sample, edge_index, edge_type)
+    g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder)
     model._graphed = g
     return g

@@ -26,6 +26,42 @@ from .nn import CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, 
 
 logger = logging.getLogger(__name__)
 
+# static sizes of a captured text-encoder batch: sequences / tokens / attention work items are padded up to multiples of these
+ENCODER_BUCKET = (64, 2048, 32)
+
+
+def bucketed_layout(lens: Sequence[int], cap: int, short_groups: bool, quanta=None):
+    """Pad a packed batch of ``lens`` (host ints, every one <= cap) to STATIC sizes, so that batches with different active sets
+    share one hipGraph per size bucket (gmlm_amd/graphs.py): dummy sequences of [PAD] tokens are appended until the sequence
+    count is a multiple of 64 AND the token count a multiple of 2,048.  A dummy is an ordinary sequence of 1..cap rows to every
+    kernel; it is pooled into a sink row behind the node table, so it reaches no output and gets a zero gradient.
+    Returns (all lengths, S_b, T_b, attention work-item boundaries int32 [G_b + 1] or None)."""
+    sq, tq, gq = quanta or ENCODER_BUCKET
+    cap = max(int(cap), 16)
+    n_real, total = len(lens), int(sum(lens))
+    k_min = -(-(tq - 1) // (cap - 1)) + 1              # dummies needed in the worst case: k + tq - 1 pad tokens in k sequences of <= cap
+    s_b = -(-(n_real + k_min) // sq) * sq
+    k = s_b - n_real
+    t_b = -(-(total + k) // tq) * tq                   # every dummy holds at least one token
+    pad = t_b - total
+    base, rem = divmod(pad, k)
+    assert base + (1 if rem else 0) <= cap and base >= 1
+    lens_all = [int(v) for v in lens] + [base + 1] * rem + [base] * (k - rem)
+    if not short_groups:
+        return lens_all, s_b, t_b, None
+    b = ops.pack_sequence_groups(lens_all).tolist()
+    g_b = min(-(-(len(b) - 1) // gq) * gq, s_b)
+    need = g_b - (len(b) - 1)
+    while need > 0:                                    # split work items until their count is the bucket's (a single sequence is the floor)
+        out = [b[0]]
+        for lo, hi in zip(b[:-1], b[1:]):
+            if need > 0 and hi - lo >= 2:
+                out.append(lo + (hi - lo) // 2)
+                need -= 1
+            out.append(hi)
+        b = out
+    return lens_all, s_b, t_b, torch.tensor(b, dtype=torch.int32)
+
 
 class TokenizedTexts:
     """Device-resident tokenisation of all node texts (replaces per-step host tokenisation and the
@@ -100,11 +136,15 @@ class GraphTextLM(nn.Module):
         self.activation_checkpointing = activation_checkpointing
         self.plm_gradient_checkpointing = plm_gradient_checkpointing
         self.plm_packed = True
+        # pad every packed text batch to the static sizes of ``bucketed_layout`` (what a captured encoder replays; set it on an
+        # eager model to run the very same padded batch without hipGraphs)
+        self.plm_bucketed = False
         # variable-length token packing in the text encoder (head dim 64 / 96)
         self.active_index = None   # set by encode_texts: ascending device index of the active nodes of the last call
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
+        self._active_seen = None  # host copy / index tables of the last active-node mask TENSOR (reused while it is not written to)
         self._graphed = None      # gmlm_amd.graphs.GraphedStep: hipGraph recording of the GNN + head regions (capture_hip_graphs)
 
     # ------------------------------------------------------------------------------------------
@@ -194,6 +234,7 @@ class GraphTextLM(nn.Module):
         """Drop the cached graph preprocessing (CSR) and tokenisation."""
         self._graphs.clear()
         self._tokens = {}
+        self._active_seen = None
 
     def start_mask_copy(self, node_mask: torch.Tensor):
         """Begin the device -> pinned-host copy of the active-node mask and mark its completion with an event.
@@ -202,6 +243,11 @@ class GraphTextLM(nn.Module):
         between, and the PLM launches follow the GNN's without an idle gap (1 ms per step at Squirrel size)."""
         if not node_mask.is_cuda:
             return node_mask, None
+        seen = self._active_seen
+        if seen is not None and seen["mask"] is node_mask and seen["version"] == node_mask._version:
+            # the very tensor of the last call, not written since (a fixed train / validation mask): its host copy is still
+            # right, so the host neither copies nor waits and keeps running ahead of the device
+            return seen["mask_h"], None
         buf = torch.empty(node_mask.numel(), dtype=torch.bool, pin_memory=True)
         buf.copy_(node_mask.reshape(-1), non_blocking=True)
         ev = torch.cuda.Event()
@@ -218,7 +264,12 @@ class GraphTextLM(nn.Module):
         mask_h, ev = _mask_copy if _mask_copy is not None else self.start_mask_copy(node_mask)
         if ev is not None:
             ev.synchronize()                                          # waits for the mask copy only
-        idx_h = mask_h.nonzero(as_tuple=True)[0]                      # host: ascending active node ids
+        seen = self._active_seen
+        if not (node_mask.is_cuda and seen is not None and seen["mask_h"] is mask_h):
+            seen = dict(mask=node_mask, version=node_mask._version, mask_h=mask_h, idx_h=mask_h.nonzero(as_tuple=True)[0],
+                        active_index=None, bucket=None)
+            self._active_seen = seen if node_mask.is_cuda else None
+        idx_h = seen["idx_h"]                                         # host: ascending active node ids
         a = idx_h.numel()
         self.active_index = None
         if a == 0:
@@ -227,7 +278,9 @@ class GraphTextLM(nn.Module):
         def to_dev(t):                                                # pinned staging: H2D copies that do not stall the host
             return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev)
 
-        self.active_index = to_dev(idx_h)                             # for the caller's loss gather (no mask indexing sync)
+        if seen["active_index"] is None:
+            seen["active_index"] = to_dev(idx_h)
+        self.active_index = seen["active_index"]                      # for the caller's loss gather (no mask indexing sync)
         cd = self._cd()
         ecfg = self.plm_encoder.config
         tokens.check_ids(ecfg.vocab_size, ecfg.max_position_embeddings)      # one sync per token set, not per step
@@ -243,7 +296,33 @@ class GraphTextLM(nn.Module):
         plm_batch_size = max(1, min(int(plm_batch_size), 65535 // heads))   # attention grids index (sequence, head) in 16 bits
         with torch.set_grad_enabled(grad and torch.is_grad_enabled()):
             # cast / fuse once, share across micro-batches (forward() has done it ahead of the GNN launches)
-            weights = _weights if _weights is not None else bert.prepare_weights(self.plm_encoder, cd)
+            weights = _weights
+            g = self._graphed if (grad and torch.is_grad_enabled() and self.training and self.dist is None) else None
+            if g is not None and not g.encoder_enabled:
+                g = None
+            if packed and a <= plm_batch_size and (self.plm_bucketed or g is not None):
+                # ONE micro-batch padded to bucket sizes: static shapes, replayable (graphs.py); the same function runs eagerly
+                hit = seen["bucket"]
+                if hit is not None and hit[0] is tokens and hit[1] == cd:
+                    key, args, short = hit[2:]                            # same mask tensor, same token set: same tables
+                else:
+                    cap = int(tokens.lens_host.max())
+                    short = cd == torch.bfloat16 and p // heads == 64 and cap <= 128
+                    lens_all, s_b, t_b, groups_h = bucketed_layout(lens_h.tolist(), cap, short)
+                    short = short and s_b * heads >= 512
+                    bi_h = torch.full((s_b,), n, dtype=torch.long)
+                    bi_h[:a] = idx_h[order]
+                    la_h = torch.tensor(lens_all, dtype=torch.int32)
+                    cu_h = torch.zeros(s_b + 1, dtype=torch.int32)
+                    cu_h[1:] = torch.cumsum(la_h, 0)
+                    args = (to_dev(la_h), to_dev(bi_h), to_dev(cu_h)) + ((to_dev(groups_h),) if short else ())
+                    key = (id(tokens), s_b, t_b, groups_h.numel() if short else 0, max(cap, 16), n)
+                    seen["bucket"] = (tokens, cd, key, args, short)
+                if g is not None:
+                    return g.encoder(self, key, tokens, args)
+                return self.encode_packed_static(tokens, key, *args, *(() if short else (None,)), weights)
+            if weights is None:
+                weights = bert.prepare_weights(self.plm_encoder, cd)
             for s in range(0, a, plm_batch_size):
                 bi = idx[s:s + plm_batch_size]
                 lh = lens_h[s:s + plm_batch_size]
@@ -288,27 +367,46 @@ class GraphTextLM(nn.Module):
                     plm_embeds = ops.MeanPoolScatter.apply(plm_embeds, hs, lens, bi)
         return plm_embeds
 
+    def encode_packed_static(self, tokens: TokenizedTexts, key, lens_all, node_of_seq, cu_all, groups=None, weights=None) -> torch.Tensor:
+        """The text-encoder pass over one bucket-padded packed batch: every shape below follows from ``key`` = (token set,
+        S_b, T_b, G_b + 1, max_len, N), every index is computed on the device from the three small tables, so the function
+        can be recorded once per bucket and replayed with other tables.  ``node_of_seq`` = N marks a dummy sequence
+        (``bucketed_layout``): its tokens are [PAD], its pooled row is the sink row N that is cut off."""
+        _, s_b, t_b, _, lmax, n = key
+        dev = lens_all.device
+        p = self.plm_encoder.config.hidden_size
+        seq = torch.repeat_interleave(torch.arange(s_b, device=dev), lens_all.long(), output_size=t_b)
+        pos = torch.arange(t_b, device=dev) - cu_all[seq].long()
+        node = node_of_seq[seq]
+        ids = tokens.input_ids
+        tok = torch.where(node < n, ids[node.clamp(max=n - 1), pos.clamp(max=ids.shape[1] - 1)], 0)
+        hs = bert.bert_encode_packed(self.plm_encoder, tok, pos, cu_all, lmax, self._cd(), self.plm_encoder.training,
+                                     self.plm_gradient_checkpointing, weights, pair_count=float(t_b) * lmax / 2, groups=groups)
+        out = torch.zeros(n + 1, p, device=dev)
+        return ops.MeanPoolScatter.apply(out, hs, None, node_of_seq, cu_all, t_b)[:n]
+
     def forward(self, gnn_input_features, edge_index, all_node_texts, text_processing_node_mask, edge_type=None,
                 plm_batch_size=8):
         mask_copy = self.start_mask_copy(text_processing_node_mask)                              # async; consumed below
         # the per-step compute-dtype copy of the PLM weights does not depend on the mask: its host-side set-up
         # (0.6 ms) runs here, under device work that is still queued, not between the GNN and the PLM launches
-        weights = bert.prepare_weights(self.plm_encoder, self._cd())
         g = self._graphed
         replay = (g is not None and self.training and torch.is_grad_enabled() and edge_type is None and self.dist is None
                   and g.matches(gnn_input_features, edge_index))
+        # (a recorded encoder casts the weights inside its own graph)
+        weights = None if (replay and g.encoder_enabled) else bert.prepare_weights(self.plm_encoder, self._cd())
         gnn_embeds = g.gnn(gnn_input_features) if replay else \
             self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)               # fp32 [N, P]
         tokens = self.tokenize(all_node_texts)
         plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)   # fp32 [N, P]
         return g.head(gnn_embeds, plm_embeds) if replay else self.head(gnn_embeds, plm_embeds)
 
-    def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor):
+    def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True):
         """Record the static-shape regions of the training step (GNN blocks + fusion; cross-attention + head) as hipGraphs
         for THIS input shape and ``edge_index`` tensor; ``forward`` then replays them (training mode, same shape, same
         edge tensor) and runs eagerly otherwise.  For the launch-bound small configurations (gmlm_amd/graphs.py)."""
         from . import graphs
-        return graphs.capture(self, gnn_input_sample, edge_index)
+        return graphs.capture(self, gnn_input_sample, edge_index, encoder=encoder)
 
     def release_hip_graphs(self):
         self._graphed = None

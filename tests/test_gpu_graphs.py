@@ -83,34 +83,95 @@ def _data(cfg, dev):
     return x, ei, y, tokens, masks
 
 
-def _step(m, x, ei, y, tokens, mask):
+def _step(m, x, ei, y, tokens, mask, plm_batch=64):
     m.zero_grad(set_to_none=True)
-    logits = m(m.soft_mask_input(x, mask, 0.7), ei, tokens, mask, plm_batch_size=64)
+    logits = m(m.soft_mask_input(x, mask, 0.7), ei, tokens, mask, plm_batch_size=plm_batch)
     loss = F.cross_entropy(logits[mask], y[mask], label_smoothing=0.2)
     loss.backward()
     return logits.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
-def test_replay_equals_eager_without_dropout(dev, cd):
+@pytest.mark.parametrize("encoder", [False, True])
+def test_replay_equals_eager_without_dropout(dev, cd, encoder):
+    """GNN + head regions (and, with ``encoder``, the text encoder recorded per size bucket) against the SAME computation run
+    eagerly.  The recorded encoder works on the bucket-padded batch (``bucketed_layout``): the eager twin runs that very
+    batch through ``plm_bucketed``; the next test ties the padded batch to the plain one."""
     cfg = _cfg(0.0)
     x, ei, y, tokens, masks = _data(cfg, dev)
     eager = build_model(cfg, dev, compute_dtype=cd).train()             # build_model: dropout_rate = 0
+    eager.plm_bucketed = encoder
     graphed = build_model(cfg, dev, compute_dtype=cd).train()
-    graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei)
-    for mask in masks:                                                   # the active set (hence the eager PLM part) changes per step
-        l0, g0 = _step(eager, x, ei, y, tokens, mask)
-        l1, g1 = _step(graphed, x, ei, y, tokens, mask)
+    g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei, encoder=encoder)
+    masks = masks + [masks[0]]                                           # ... and a bucket that is already recorded
+    for mask in masks:                                                   # the active set (hence the packed PLM batch) changes per step
+        pb = 512 if encoder else 64                                      # one packed batch (recordable) / several micro-batches (eager)
+        l0, g0 = _step(eager, x, ei, y, tokens, mask, pb)
+        l1, g1 = _step(graphed, x, ei, y, tokens, mask, pb)
         assert torch.equal(l0, l1)
         assert set(g0) == set(g1)
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+    assert (len(g._encoders) >= 1) == encoder
     graphed.eval()                                                       # evaluation falls back to the eager path
     eager.eval()
     with torch.no_grad():
         a = graphed(graphed.soft_mask_input(x, masks[0], 0.7), ei, tokens, masks[0], plm_batch_size=64)
         b = eager(eager.soft_mask_input(x, masks[0], 0.7), ei, tokens, masks[0], plm_batch_size=64)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_bucket_padding_changes_nothing_but_summation_order(dev, cd):
+    """Dummy [PAD] sequences reach no output and add exact zeros to every weight gradient: the padded batch differs from the
+    plain one only through the order of the split-K / column sums (and, in bf16, through which rows share an attention work
+    item)."""
+    cfg = _cfg(0.0)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+    plain = build_model(cfg, dev, compute_dtype=cd).train()
+    padded = build_model(cfg, dev, compute_dtype=cd).train()
+    padded.plm_bucketed = True
+    l0, g0 = _step(plain, x, ei, y, tokens, masks[1], 512)
+    l1, g1 = _step(padded, x, ei, y, tokens, masks[1], 512)
+    tol = 2e-5 if cd == torch.float32 else 2e-2
+    assert (l0 - l1).abs().max() <= tol * max(1.0, float(l0.abs().max()))
+    assert set(g0) == set(g1)
+    gmax = max(float(v.abs().max()) for v in g0.values())
+    for k in g0:
+        if k.endswith("key.bias"):                                       # mathematically zero gradient: rounding noise on both sides
+            assert float(g0[k].abs().max()) <= 1e-4 * gmax and float(g1[k].abs().max()) <= 1e-4 * gmax, k
+            continue
+        scale = max(float(g0[k].abs().max()), 1e-4 * gmax)
+        assert float((g0[k] - g1[k]).abs().max()) <= tol * scale, k
+
+
+def test_bucket_lru_and_layout_change(dev):
+    """More buckets than the LRU holds, then the first one again: recordings are dropped and re-made, results stay right."""
+    import gmlm_amd.model as gm
+    cfg = _cfg(0.0)
+    x, ei, y, tokens, _ = _data(cfg, dev)
+    gen = torch.Generator().manual_seed(3)
+    n = cfg["n"]
+    fracs = (0.05, 0.3, 0.55, 0.8, 0.95, 0.05)
+    masks = [(torch.rand(n, generator=gen) < f).to(dev) for f in fracs[:-1]]
+    masks.append(masks[0])
+    eager = build_model(cfg, dev, compute_dtype=torch.float32).train()
+    eager.plm_bucketed = True
+    graphed = build_model(cfg, dev, compute_dtype=torch.float32).train()
+    old = gm.ENCODER_BUCKET
+    gm.ENCODER_BUCKET = (16, 256, 8)                                     # small quanta: every mask above lands in its own bucket
+    try:
+        g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei)
+        g.encoder_buckets = 2
+        for mask in masks:
+            l0, g0 = _step(eager, x, ei, y, tokens, mask, 512)
+            l1, g1 = _step(graphed, x, ei, y, tokens, mask, 512)
+            assert torch.equal(l0, l1)
+            for k in g0:
+                assert torch.equal(g0[k], g1[k]), k
+            assert len(g._encoders) <= 2
+    finally:
+        gm.ENCODER_BUCKET = old
 
 
 def test_replays_draw_fresh_dropout_masks(dev):

@@ -86,3 +86,29 @@ def test_tokenize_cache_is_constant_time_per_step_and_notices_changes():
     assert t3 is not t2 and calls[-1] == 1001 and int(t3.lens_host[0]) == 5
     m.clear_caches()
     assert m.tokenize(texts) is not t3
+
+
+def test_bucketed_layout_invariants():
+    """Static sizes of a captured text-encoder batch (gmlm_amd/model.py::bucketed_layout): multiples of the quanta, every
+    dummy sequence within 1..cap tokens, work items cover all sequences within the kernels' limits."""
+    from gmlm_amd import ops
+    from gmlm_amd.model import bucketed_layout
+    rng = np.random.default_rng(0)
+    for n_real, cap, quanta in ((0, 12, None), (1, 128, None), (548, 128, None), (700, 40, (16, 256, 8)), (63, 16, (64, 2048, 32)),
+                                (5, 3, (8, 64, 4))):
+        lens = rng.integers(1, cap + 1, n_real).tolist()
+        la, s_b, t_b, groups = bucketed_layout(lens, cap, True, quanta)
+        sq, tq, gq = quanta or (64, 2048, 32)
+        c = max(cap, 16)
+        assert la[:n_real] == lens and len(la) == s_b and sum(la) == t_b
+        assert s_b % sq == 0 and t_b % tq == 0 and s_b > n_real
+        assert all(1 <= v <= c for v in la[n_real:])
+        b = groups.tolist()
+        assert b[0] == 0 and b[-1] == s_b and all(x < y for x, y in zip(b[:-1], b[1:]))
+        assert (len(b) - 1) % gq == 0 or len(b) - 1 == s_b
+        for lo, hi in zip(b[:-1], b[1:]):
+            assert hi - lo <= ops.SHORT_GROUP_SEQS and sum(la[lo:hi]) <= ops.SHORT_GROUP_ROWS
+        # same bucket for a slightly different active set
+        la2, s2, t2, g2 = bucketed_layout(lens[:-1] if lens else lens, cap, True, quanta)
+        assert (s2, t2) == (s_b, t_b) or n_real == 0 or abs(s2 - s_b) == sq or abs(t2 - t_b) == tq
+    assert bucketed_layout([5, 7], 12, False)[3] is None
