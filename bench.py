@@ -525,6 +525,7 @@ def main():
     ap.add_argument("--cpu-plm-sample", type=int, default=64)
     ap.add_argument("--cpu-hc", type=int, default=768)
     ap.add_argument("--no-encoder-graph", action="store_true", help="with hipGraphs: leave the text encoder eager (GNN + head regions only)")
+    ap.add_argument("--no-whole-step-graph", action="store_true", help="with hipGraphs: three separate regions instead of ONE graph with the encoder and GNN branches side by side")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile the timed steps (host side) and write the top entries to FILE")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the kernel micro-benchmarks (rank 0, N=1 only)")
@@ -608,7 +609,8 @@ def main():
     if args.hip_graph:
         if distributed:
             raise SystemExit("--hip-graph is single-GPU")
-        model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei, encoder=not args.no_encoder_graph)
+        model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei, encoder=not args.no_encoder_graph,
+                                 whole_step=not args.no_whole_step_graph)
 
     def step():
         model.zero_grad(set_to_none=True)

@@ -120,13 +120,12 @@ template <int D, bool DROP, int R>
 __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
   using T = bf16_t;
   static_assert(D == 64, "dense swizzled images are laid out for d = 64");
-  constexpr int NT = 2 * R, PITCH = D, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;   // dense rows: 48 KB at R = 128 = three workgroups per CU
+  constexpr int NT = 2 * R, PITCH = D, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* tk = reinterpret_cast<T*>(smem_raw);
   T* tv = tk + R * PITCH;
-  T* tq = tv + R * PITCH;
   ShortMeta mt;
-  mt.q2k_lo = reinterpret_cast<int16_t*>(tq + R * PITCH);
+  mt.q2k_lo = reinterpret_cast<int16_t*>(tv + R * PITCH);
   mt.q2k_hi = mt.q2k_lo + R; mt.k2q_lo = mt.q2k_hi + R; mt.k2q_hi = mt.k2q_lo + R;
   mt.qid = reinterpret_cast<uint8_t*>(mt.k2q_hi + R);
   mt.kid = mt.qid + R;
@@ -138,16 +137,21 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
   const T* qg = static_cast<const T*>(p.q) + qbase * p.q_stride + hd * D;
   const T* kg = static_cast<const T*>(p.k) + kbase * p.k_stride + hd * D;
   const T* vg = static_cast<const T*>(p.v) + kbase * p.v_stride + hd * D;
-  uint4 rk[PER], rv[PER], rq[PER];
+  // Only K and V are staged (they are MFMA A operands of every wave): 32 KB at R = 128 = five workgroups per CU, and with them
+  // five items' worth of loads in flight per CU.  A query row is used by its own lane pair alone: it goes from global memory
+  // straight into the B-operand registers, issued together with the K / V loads.
+  const int q_row = w * 32 + r;
+  RowFrag<T, D> qf;
+  qf.load(qg + (uint32_t)((q_row < nq ? q_row : 0) * (int)p.q_stride), q_row < nq, h);
+  uint4 rk[PER], rv[PER];
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
     const int i = tid + k * NT, row = i / CPR, col = (i % CPR) * 8;
-    rk[k] = rv[k] = rq[k] = make_uint4(0, 0, 0, 0);
+    rk[k] = rv[k] = make_uint4(0, 0, 0, 0);
     if (row < nk) {
       rk[k] = *reinterpret_cast<const uint4*>(kg + (uint32_t)(row * (int)p.k_stride + col));
       rv[k] = *reinterpret_cast<const uint4*>(vg + (uint32_t)(row * (int)p.v_stride + col));
     }
-    if (row < nq) rq[k] = *reinterpret_cast<const uint4*>(qg + (uint32_t)(row * (int)p.q_stride + col));
   }
 #pragma unroll
   for (int k = 0; k < PER; ++k) {
@@ -155,14 +159,9 @@ __global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
     const int c = i % CPR;                                      // 16-byte chunk of the row -> swizzled slot (attn_common.hpp)
     *reinterpret_cast<uint4*>(tk + row * PITCH + ((c ^ sw_row(row)) << 3)) = rk[k];
     *reinterpret_cast<uint4*>(tv + row * PITCH + ((c ^ sw_tr(row)) << 3)) = rv[k];
-    *reinterpret_cast<uint4*>(tq + row * PITCH + ((c ^ sw_row(row)) << 3)) = rq[k];
   }
   __syncthreads();
   if (w * 32 >= nq) return;                                   // (no barrier below)
-  const int q_row = w * 32 + r;
-  RowFrag<T, D> qf;
-#pragma unroll
-  for (int s = 0; s < D / 16; ++s) qf.v[s] = *reinterpret_cast<const bf16x8*>(tq + q_row * PITCH + (((2 * s + h) ^ sw_row(q_row)) << 3));
   const bf16x8 qm = antihot_frag(mt.qid[q_row], h);
   int b0, b1;
   block_range(mt.q2k_lo, mt.q2k_hi, w, nq, b0, b1);           // key blocks that hold a key of this wave's sequences
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(2 * R, R >= 96 ? 2 : 3) void attn_bwd_short_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static size_t fwd_lds(int r) { return (size_t)3 * r * 64 * sizeof(bf16_t) + (size_t)r * (4 * sizeof(int16_t) + 2); }
+static size_t fwd_lds(int r) { return (size_t)2 * r * 64 * sizeof(bf16_t) + (size_t)r * (4 * sizeof(int16_t) + 2); }
 static size_t bwd_lds(int r) {
   return (size_t)4 * r * (64 + 8) * sizeof(bf16_t) + 2 * r * sizeof(float) + 3 * r * sizeof(bf16_t) + (size_t)r * (4 * sizeof(int16_t) + 2);
 }

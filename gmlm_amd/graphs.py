@@ -68,7 +68,7 @@ class GraphedStep:
     ``head(gnn_embeds, plm_embeds)`` -> logits; both are autograd-aware graph replays."""
 
     def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-                 encoder: bool = True):
+                 encoder: bool = True, whole_step: bool = True):
         if model.dist is not None:
             raise ValueError("hipGraph capture is single-GPU: collectives of the node partition are not captured")
         if not model.training:
@@ -79,6 +79,11 @@ class GraphedStep:
         self.encoder_enabled = bool(encoder)
         self.encoder_buckets = 4                         # recordings kept (LRU)
         self._encoders = {}                              # bucket key -> (token set, graphed region)
+        self.whole_step = bool(whole_step) and self.encoder_enabled
+        self._steps = {}                                 # bucket key -> (token set, graphed whole-forward region)
+        self._side = torch.cuda.Stream(device=dev)
+        self._side2 = torch.cuda.Stream(device=dev)
+        self._graph_args = (edge_index, edge_type)
         model.graph(edge_index, xm_sample.size(0), edge_type).active_index    # CSR build (sort, host syncs) happens before capture
         p_dim = model.plm_encoder.config.hidden_size
         n = xm_sample.size(0)
@@ -116,17 +121,61 @@ class GraphedStep:
         self._encoders[key] = hit                                           # most recently used last
         return hit[1](*tables)
 
+    def step(self, model, key, tokens, xm, tables):
+        """Replay (recording it first if needed) the WHOLE forward of bucket ``key``: text encoder and GNN as two branches that
+        fork after the seed bump and join ahead of the head, so the device runs their (small) kernels side by side; autograd
+        runs each backward node on its forward stream, so the recorded backward has the same two branches."""
+        hit = self._steps.get(key)
+        if hit is None or hit[0] is not tokens:
+            side = self._side
+            edge_index, edge_type = self._graph_args
+
+            def step_fn(x, *t):
+                model._branch_stream = self._side2
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)                                        # fork (behind the seed bump of _Region.forward)
+                # the branch on the side stream is issued LAST: autograd then runs its backward FIRST (latest forward nodes
+                # first), so when the engine reaches the GNN's backward the encoder's is already queued on `side` and waits for
+                # nothing but the head's gradient
+                gnn = model.get_graph_embeddings(x, edge_index, edge_type)
+                with torch.cuda.stream(side):
+                    plm = model.encode_packed_static(tokens, key, *t)
+                cur.wait_stream(side)                                        # join
+                # plm's block belongs to `side`'s pool but its last readers (the head, and the head's backward through its saved
+                # tensors) run on `cur`: without this the allocator hands the block to the next allocation on `side` - an encoder
+                # backward temporary, on the branch that runs BESIDE the head's backward - as soon as the tensor dies
+                plm.record_stream(cur)
+                try:
+                    return model.head(gnn, plm)
+                finally:
+                    model._branch_stream = None
+
+            xs = xm.detach().clone().requires_grad_(True)
+            samples = (xs,) + tuple(t.clone() for t in tables)
+            used = _touched_params(model, lambda: step_fn(*samples).sum().backward())
+            xs.grad = None
+            region = torch.cuda.make_graphed_callables(_Region(step_fn, used, self.counter, True), samples, num_warmup_iters=2)
+            while len(self._steps) >= self.encoder_buckets:
+                self._steps.pop(next(iter(self._steps)))
+            hit = (tokens, region)
+        else:
+            self._steps.pop(key)
+        self._steps[key] = hit
+        return hit[1](xm, *tables)
+
     def matches(self, xm: torch.Tensor, edge_index: torch.Tensor) -> bool:
         return self.key == (tuple(xm.shape), xm.dtype, edge_index.data_ptr(), edge_index._version, tuple(edge_index.shape))
 
 
 def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-            encoder: bool = True) -> GraphedStep:
+            encoder: bool = True, whole_step: bool = True) -> GraphedStep:
     """Record the GNN and head regions for this (soft-masked input shape, graph) and attach them to ``model``:
     ``model.forward`` replays them whenever it is called in training mode with an input of the same shape / dtype and the
     same ``edge_index`` tensor; any other call runs eagerly.  ``encoder``: also record the text encoder, per size bucket, the
-    first time a step needs that bucket.  ``model.release_hip_graphs()`` drops the recordings."""
+    first time a step needs that bucket; ``whole_step``: record encoder + GNN + head as ONE graph per bucket whose encoder and
+    GNN branches run side by side (``GraphedStep.step``; a step whose text batch needs several micro-batches falls back to the
+    separate regions).  ``model.release_hip_graphs()`` drops the recordings."""
     model._graphed = None
-    g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder)
+    g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder, whole_step)
     model._graphed = g
     return g

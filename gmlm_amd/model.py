@@ -144,6 +144,7 @@ class GraphTextLM(nn.Module):
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
+        self._branch_stream = None  # side stream for the second cross-attention while a whole-step hipGraph is recorded (graphs.py)
         self._active_seen = None  # host copy / index tables of the last active-node mask TENSOR (reused while it is not written to)
         self._graphed = None      # gmlm_amd.graphs.GraphedStep: hipGraph recording of the GNN + head regions (capture_hip_graphs)
 
@@ -254,14 +255,10 @@ class GraphTextLM(nn.Module):
         ev.record()
         return buf, ev
 
-    def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8,
-                     _mask_copy=None, _weights=None) -> torch.Tensor:
-        """main.py:328-358: PLM over the active nodes in micro-batches, masked mean pool, row scatter."""
-        n = node_mask.numel()
-        dev = node_mask.device
-        p = self.plm_encoder.config.hidden_size
-        plm_embeds = torch.zeros(n, p, device=dev)
-        mask_h, ev = _mask_copy if _mask_copy is not None else self.start_mask_copy(node_mask)
+    def _active_set(self, node_mask: torch.Tensor, mask_copy=None) -> dict:
+        """Host view of the active-node mask: waits for the mask copy (``start_mask_copy``) unless this very tensor was seen
+        last call and has not been written since; caches what is derived from it (index tables of the packed text batch)."""
+        mask_h, ev = mask_copy if mask_copy is not None else self.start_mask_copy(node_mask)
         if ev is not None:
             ev.synchronize()                                          # waits for the mask copy only
         seen = self._active_seen
@@ -269,6 +266,47 @@ class GraphTextLM(nn.Module):
             seen = dict(mask=node_mask, version=node_mask._version, mask_h=mask_h, idx_h=mask_h.nonzero(as_tuple=True)[0],
                         active_index=None, bucket=None)
             self._active_seen = seen if node_mask.is_cuda else None
+        return seen
+
+    def _bucket_tables(self, tokens: TokenizedTexts, seen: dict, cd):
+        """Index tables of the ONE bucket-padded packed batch that holds every active node (``bucketed_layout``):
+        (key, device tables, short-sequence attention used)."""
+        hit = seen["bucket"]
+        if hit is not None and hit[0] is tokens and hit[1] == cd:
+            return hit[2:]                                            # same mask tensor, same token set: same tables
+        idx_h = seen["idx_h"]
+        a, n = idx_h.numel(), seen["mask_h"].numel()
+        dev = tokens.input_ids.device
+        cfg = self.plm_encoder.config
+        heads, p = cfg.num_attention_heads, cfg.hidden_size
+        lens_h = tokens.lens_host[idx_h]
+        order = torch.argsort(lens_h, descending=True, stable=True)   # long sequences first: fuller attention work items
+        cap = int(tokens.lens_host.max())
+        short = cd == torch.bfloat16 and p // heads == 64 and cap <= 128
+        lens_all, s_b, t_b, groups_h = bucketed_layout(lens_h[order].tolist(), cap, short)
+        short = short and s_b * heads >= 512
+        bi_h = torch.full((s_b,), n, dtype=torch.long)
+        bi_h[:a] = idx_h[order]
+        la_h = torch.tensor(lens_all, dtype=torch.int32)
+        cu_h = torch.zeros(s_b + 1, dtype=torch.int32)
+        cu_h[1:] = torch.cumsum(la_h, 0)
+
+        def to_dev(t):
+            return t.pin_memory().to(dev, non_blocking=True) if dev.type == "cuda" else t.to(dev)
+
+        args = (to_dev(la_h), to_dev(bi_h), to_dev(cu_h)) + ((to_dev(groups_h),) if short else ())
+        key = (id(tokens), s_b, t_b, groups_h.numel() if short else 0, max(cap, 16), n)
+        seen["bucket"] = (tokens, cd, key, args, short)
+        return key, args, short
+
+    def encode_texts(self, tokens: TokenizedTexts, node_mask: torch.Tensor, plm_batch_size: int = 8,
+                     _mask_copy=None, _weights=None) -> torch.Tensor:
+        """main.py:328-358: PLM over the active nodes in micro-batches, masked mean pool, row scatter."""
+        n = node_mask.numel()
+        dev = node_mask.device
+        p = self.plm_encoder.config.hidden_size
+        plm_embeds = torch.zeros(n, p, device=dev)
+        seen = self._active_set(node_mask, _mask_copy)
         idx_h = seen["idx_h"]                                         # host: ascending active node ids
         a = idx_h.numel()
         self.active_index = None
@@ -284,12 +322,6 @@ class GraphTextLM(nn.Module):
         cd = self._cd()
         ecfg = self.plm_encoder.config
         tokens.check_ids(ecfg.vocab_size, ecfg.max_position_embeddings)      # one sync per token set, not per step
-        lens_h = tokens.lens_host[idx_h]
-        # length-bucketed micro-batches: every active node is encoded independently and scattered by its own
-        # index, so the order is free; sorting by token count keeps the padding of each micro-batch small
-        order = torch.argsort(lens_h, descending=True, stable=True)
-        lens_h = lens_h[order]
-        idx = to_dev(idx_h[order])
         grad = self.plm_encoder.training or self.training
         heads = self.plm_encoder.config.num_attention_heads
         packed = (p // heads) in (64, 96) and self.plm_packed
@@ -302,27 +334,18 @@ class GraphTextLM(nn.Module):
                 g = None
             if packed and a <= plm_batch_size and (self.plm_bucketed or g is not None):
                 # ONE micro-batch padded to bucket sizes: static shapes, replayable (graphs.py); the same function runs eagerly
-                hit = seen["bucket"]
-                if hit is not None and hit[0] is tokens and hit[1] == cd:
-                    key, args, short = hit[2:]                            # same mask tensor, same token set: same tables
-                else:
-                    cap = int(tokens.lens_host.max())
-                    short = cd == torch.bfloat16 and p // heads == 64 and cap <= 128
-                    lens_all, s_b, t_b, groups_h = bucketed_layout(lens_h.tolist(), cap, short)
-                    short = short and s_b * heads >= 512
-                    bi_h = torch.full((s_b,), n, dtype=torch.long)
-                    bi_h[:a] = idx_h[order]
-                    la_h = torch.tensor(lens_all, dtype=torch.int32)
-                    cu_h = torch.zeros(s_b + 1, dtype=torch.int32)
-                    cu_h[1:] = torch.cumsum(la_h, 0)
-                    args = (to_dev(la_h), to_dev(bi_h), to_dev(cu_h)) + ((to_dev(groups_h),) if short else ())
-                    key = (id(tokens), s_b, t_b, groups_h.numel() if short else 0, max(cap, 16), n)
-                    seen["bucket"] = (tokens, cd, key, args, short)
+                key, args, short = self._bucket_tables(tokens, seen, cd)
                 if g is not None:
                     return g.encoder(self, key, tokens, args)
                 return self.encode_packed_static(tokens, key, *args, *(() if short else (None,)), weights)
             if weights is None:
                 weights = bert.prepare_weights(self.plm_encoder, cd)
+            lens_h = tokens.lens_host[idx_h]
+            # length-bucketed micro-batches: every active node is encoded independently and scattered by its own
+            # index, so the order is free; sorting by token count keeps the padding of each micro-batch small
+            order = torch.argsort(lens_h, descending=True, stable=True)
+            lens_h = lens_h[order]
+            idx = to_dev(idx_h[order])
             for s in range(0, a, plm_batch_size):
                 bi = idx[s:s + plm_batch_size]
                 lh = lens_h[s:s + plm_batch_size]
@@ -393,6 +416,24 @@ class GraphTextLM(nn.Module):
         g = self._graphed
         replay = (g is not None and self.training and torch.is_grad_enabled() and edge_type is None and self.dist is None
                   and g.matches(gnn_input_features, edge_index))
+        if replay and g.whole_step:
+            # ONE recording of the whole forward (and of its backward) per size bucket of the text batch, with the text encoder
+            # and the GNN on two branches of the graph (graphs.py).  The host needs the active set first: it waits for the mask
+            # copy here, ahead of every launch of the step - unless this mask tensor is the one of the last call, unwritten.
+            tokens = self.tokenize(all_node_texts)
+            seen = self._active_set(text_processing_node_mask, mask_copy)
+            heads = self.plm_encoder.config.num_attention_heads
+            a = seen["idx_h"].numel()
+            if (0 < a <= max(1, min(int(plm_batch_size), 65535 // heads)) and self.plm_packed
+                    and (self.plm_encoder.config.hidden_size // heads) in (64, 96)):
+                if seen["active_index"] is None:
+                    seen["active_index"] = seen["idx_h"].pin_memory().to(gnn_input_features.device, non_blocking=True)
+                self.active_index = seen["active_index"]
+                ecfg = self.plm_encoder.config
+                tokens.check_ids(ecfg.vocab_size, ecfg.max_position_embeddings)
+                key, args, _ = self._bucket_tables(tokens, seen, self._cd())
+                return g.step(self, key, tokens, gnn_input_features, args)
+            mask_copy = (seen["mask_h"], None)                        # already on the host
         # (a recorded encoder casts the weights inside its own graph)
         weights = None if (replay and g.encoder_enabled) else bert.prepare_weights(self.plm_encoder, self._cd())
         gnn_embeds = g.gnn(gnn_input_features) if replay else \
@@ -401,12 +442,13 @@ class GraphTextLM(nn.Module):
         plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)   # fp32 [N, P]
         return g.head(gnn_embeds, plm_embeds) if replay else self.head(gnn_embeds, plm_embeds)
 
-    def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True):
+    def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True,
+                           whole_step: bool = True):
         """Record the static-shape regions of the training step (GNN blocks + fusion; cross-attention + head) as hipGraphs
         for THIS input shape and ``edge_index`` tensor; ``forward`` then replays them (training mode, same shape, same
         edge tensor) and runs eagerly otherwise.  For the launch-bound small configurations (gmlm_amd/graphs.py)."""
         from . import graphs
-        return graphs.capture(self, gnn_input_sample, edge_index, encoder=encoder)
+        return graphs.capture(self, gnn_input_sample, edge_index, encoder=encoder, whole_step=whole_step)
 
     def release_hip_graphs(self):
         self._graphed = None
@@ -419,8 +461,25 @@ class GraphTextLM(nn.Module):
         ring = self.dist.ring_attention if (self.dist is not None and self.dist.use_ring) else None
         gather = self.dist.all_gather_rows if (self.dist is not None and ring is None) else None
         self.graph_to_text_attn.compute_dtype = self.text_to_graph_attn.compute_dtype = cd
+        bs = self._branch_stream if self.dist is None else None
+        if bs is not None:
+            # whole-step recording (graphs.py): the two cross-attentions are independent - the second one goes to a branch of
+            # the graph.  The fork is taken BEFORE the first module's launches; the branch is issued last, so that its backward
+            # is queued first (see GraphedStep.step)
+            cur = torch.cuda.current_stream()
+            bs.wait_stream(cur)
         gnn_attended = self.graph_to_text_attn(g, t, gather, ring)
-        text_attended = self.text_to_graph_attn(t, g, gather, ring)
+        if bs is not None:
+            with torch.cuda.stream(bs):
+                text_attended = self.text_to_graph_attn(t, g, gather, ring)
+            cur.wait_stream(bs)
+            # blocks read or written on a stream other than the one that allocated them (the module's saved inputs are read by
+            # its backward on `bs`): keep the allocator from recycling them on their own stream while the other still runs
+            gnn_embeds.record_stream(bs)
+            plm_embeds.record_stream(bs)
+            text_attended.record_stream(cur)
+        else:
+            text_attended = self.text_to_graph_attn(t, g, gather, ring)
         fn = self.fusion_network
         pdim = gnn_attended.shape[-1]
         w = fn[0].weight

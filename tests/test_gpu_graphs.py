@@ -92,7 +92,7 @@ def _step(m, x, ei, y, tokens, mask, plm_batch=64):
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("encoder", [False, True])
+@pytest.mark.parametrize("encoder", [False, True, "whole"])
 def test_replay_equals_eager_without_dropout(dev, cd, encoder):
     """GNN + head regions (and, with ``encoder``, the text encoder recorded per size bucket) against the SAME computation run
     eagerly.  The recorded encoder works on the bucket-padded batch (``bucketed_layout``): the eager twin runs that very
@@ -100,9 +100,10 @@ def test_replay_equals_eager_without_dropout(dev, cd, encoder):
     cfg = _cfg(0.0)
     x, ei, y, tokens, masks = _data(cfg, dev)
     eager = build_model(cfg, dev, compute_dtype=cd).train()             # build_model: dropout_rate = 0
-    eager.plm_bucketed = encoder
+    eager.plm_bucketed = bool(encoder)
     graphed = build_model(cfg, dev, compute_dtype=cd).train()
-    g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei, encoder=encoder)
+    g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei, encoder=bool(encoder),
+                                   whole_step=encoder == "whole")
     masks = masks + [masks[0]]                                           # ... and a bucket that is already recorded
     for mask in masks:                                                   # the active set (hence the packed PLM batch) changes per step
         pb = 512 if encoder else 64                                      # one packed batch (recordable) / several micro-batches (eager)
@@ -112,7 +113,7 @@ def test_replay_equals_eager_without_dropout(dev, cd, encoder):
         assert set(g0) == set(g1)
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
-    assert (len(g._encoders) >= 1) == encoder
+    assert (len(g._encoders) >= 1) == (encoder is True) and (len(g._steps) >= 1) == (encoder == "whole")
     graphed.eval()                                                       # evaluation falls back to the eager path
     eager.eval()
     with torch.no_grad():
@@ -161,7 +162,7 @@ def test_bucket_lru_and_layout_change(dev):
     old = gm.ENCODER_BUCKET
     gm.ENCODER_BUCKET = (16, 256, 8)                                     # small quanta: every mask above lands in its own bucket
     try:
-        g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei)
+        g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei, whole_step=False)
         g.encoder_buckets = 2
         for mask in masks:
             l0, g0 = _step(eager, x, ei, y, tokens, mask, 512)
