@@ -352,7 +352,7 @@ def _profile_json(names):
 
 def _pmc_traffic(key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/rNN_spmm_traffic.json); None if absent."""
-    d, _ = _profile_json(["r02_spmm_traffic.json", "r01_spmm_traffic.json"])
+    d, _ = _profile_json(["r03_spmm_traffic.json", "r02_spmm_traffic.json", "r01_spmm_traffic.json"])
     return d.get(key, {}).get("hbm_bytes_per_launch")
 
 
@@ -360,7 +360,7 @@ def _pmc_attn(kernel_prefix, grid=None):
     """PMC MFMA-busy fraction (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 1024 SIMDs)) of an attention kernel from the
     committed profile (profiles/rNN_attn_pmc.json, made by tools/pmc_attn.py); None if absent.  ``grid``: total threads of the
     launch (several shapes run the same kernel in the profile)."""
-    d, name = _profile_json(["r02_attn_pmc.json"])
+    d, name = _profile_json(["r03_attn_pmc.json", "r02_attn_pmc.json"])
     for k, v in d.items():
         if k.startswith(kernel_prefix) and (grid is None or k.endswith("grid=%d" % grid)):
             return {"mfma_busy": v.get("mfma_util"), "mfma_busy_useful_flops": v.get("mfma_util_useful"), "valu_per_mfma": v.get("valu_per_mfma"),
@@ -710,6 +710,14 @@ def main():
             sp_bw.pop("frac_hbm_peak", None)
             sp_bw.update({"regime": "cache-resident dH (8-32 MB): reported against the L2 / Infinity-Cache gather rate, not HBM",
                           "bound": "l2/mall", "peak_GBps": 17000.0, "frac_l2_gather_rate": round(sp_bw["algorithmic_GBps"] / 17000.0, 4)})
+        for nm in ("attn_fwd_d64", "attn_bwd_d64"):
+            k = kern.get(nm)
+            if k is not None and "algorithmic_GBps" in k and args.max_len <= 128:
+                # sequences of <= 128 tokens: 4 L d flops per 8 d bytes of q, k, v, o = L / 2 <= 64 flop/B, far below the ridge
+                # (2.5 PF / 8 TB/s = 312): these launches are priced against HBM, not MFMA
+                k["bound"] = "hbm"
+                k["note"] = ("text-encoder attention at <= 128 tokens per sequence: <= 64 flop per byte of q/k/v/o, a fifth of the MFMA/HBM "
+                             "ridge (312): HBM-side kernel; frac_mfma_peak is reported for completeness only")
         out["kernels"] = kern
     if rank == 0 and world == 1 and not args.no_micro and args.workload == "squirrel":
         del model
@@ -733,11 +741,11 @@ def main():
                 "cross_attention_fwd": {"kernel": "attn_fwd_pipe_kernel<96, 8> (h=8, d=96, N=20,804, no mask: padded = executed flops)",
                                         "achieved": xa["fwd_TFLOPs"], "frac": xa["fwd_frac_mfma_peak"], "avg_launch_ms": xa["fwd_ms"],
                                         "pmc": _pmc_attn("attn_fwd_pipe_kernel<96, 8", 82 * 8 * 512)},
-                "cross_attention_bwd": {"kernel": "attn_delta + attn_bwd_dq + attn_bwd_dkv (10 B h L^2 d convention; 14 executed: S is recomputed in both)",
+                "cross_attention_bwd": {"kernel": "attn_delta + attn_bwd_dq_pipe<96, 8> + attn_bwd_dkv_pipe<96, 8> (10 B h L^2 d convention; 14 executed: S is recomputed in both)",
                                         "achieved": xa["bwd_TFLOPs"], "frac": xa["bwd_frac_mfma_peak"], "avg_launch_ms": xa["bwd_ms"],
                                         "executed_TFLOPs": round(xa["bwd_TFLOPs"] * 1.4, 1),
-                                        "pmc_dq": _pmc_attn("attn_bwd_dq_kernel<unsigned short, 96, 8", 82 * 8 * 512),
-                                        "pmc_dkv": _pmc_attn("attn_bwd_dkv_kernel<unsigned short, 96, 8", 82 * 8 * 512)},
+                                        "pmc_dq": _pmc_attn("attn_bwd_dq_pipe_kernel<96, 8", 82 * 8 * 512),
+                                        "pmc_dkv": _pmc_attn("attn_bwd_dkv_pipe_kernel<96, 8", 82 * 8 * 512)},
                 "masked_mha_fwd": {"kernel": "attn_fwd_pipe_kernel<64, 4> (B=32, h=12, L=512, d=64, kv_len ~ U[256,512])",
                                    "achieved_padded": mh["fwd_TFLOPs"], "frac_padded": mh["fwd_frac_mfma_peak"],
                                    "achieved_executed": mh.get("fwd_TFLOPs_executed"), "avg_launch_ms": mh["fwd_ms"],

@@ -450,7 +450,8 @@ class AttentionQKV(torch.autograd.Function):
             groups = None                                       # only the short-sequence kernels pack sequences into work items
         n_groups = 0 if groups is None else groups.numel() - 1
         out_lo = torch.empty_like(out) if (qkv.dtype == torch.bfloat16 and not short and qkv.requires_grad) else None
-        with _span("attn_fwd_d%d" % d, flops=flops):
+        nb = out.numel() * out.element_size()                   # one of q, k, v, o
+        with _span("attn_fwd_d%d" % d, flops=flops, bytes=(4 + (1 if out_lo is not None else 0)) * nb):
             sd = ctx.sd = _sd()
             check(lib().gmlm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(kv_len), b, h, l, l, d, hd3, hd3, hd3, float(scale),
                                            float(p), seed, sd, _ptr(out), _ptr(out_lo), _ptr(lse), _dt(qkv), _ptr(cu_seqlens),
@@ -490,7 +491,8 @@ class AttentionQKV(torch.autograd.Function):
         if fused_db:
             part = _ws(4 * (n_groups or b) * hd3, qkv.device).view(torch.float32)
             db = torch.empty(hd3, dtype=torch.float32, device=qkv.device)
-        with _span("attn_bwd_d%d" % d, flops=2.5 * flops):
+        # q, k, v, dO in; dq, dk, dv out (+ o, o_lo on the streaming path, which forms delta from them)
+        with _span("attn_bwd_d%d" % d, flops=2.5 * flops, bytes=(7 + (0 if ctx.short else 2)) * qkv.numel() // 3 * qkv.element_size()):
             sd = ctx.sd
             check(lib().gmlm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(gout), _ptr(lse), _ptr(kv_len), b, h,
                                            l, l, d, hd3, hd3, hd3, scale, p, seed, sd, _ptr(dq), _ptr(dk), _ptr(dv), hd3, hd3,
