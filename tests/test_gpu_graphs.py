@@ -199,3 +199,33 @@ def test_replays_draw_fresh_dropout_masks(dev):
         assert torch.isfinite(logits).all() and all(torch.isfinite(v).all() for v in grads.values())
         losses.append(float(F.cross_entropy(logits[mask], y[mask])))
     assert len(set(losses)) == len(losses)
+    # the whole-step recording (one micro-batch): the SAME mask twice draws two different dropout masks, a third call with
+    # another active set records / replays another bucket or the same one with other tables; gradients stay finite and the
+    # active index follows the mask
+    outs = []
+    for mask in (masks[0], masks[0], masks[1]):
+        logits, grads = _step(m, x, ei, y, tokens, mask, 512)
+        assert torch.isfinite(logits).all() and all(torch.isfinite(v).all() for v in grads.values())
+        assert torch.equal(m.active_index, mask.nonzero(as_tuple=True)[0])
+        outs.append(logits)
+    assert len(g._steps) >= 1
+    assert not torch.equal(outs[0], outs[1])
+
+
+def test_mask_tensor_cache_notices_in_place_writes(dev):
+    """The host copy of the active set is reused only for the very same, unwritten mask tensor (identity + version counter)."""
+    cfg = _cfg(0.0)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+    m = build_model(cfg, dev, compute_dtype=torch.float32).train()
+    ref = build_model(cfg, dev, compute_dtype=torch.float32).train()
+    mask = masks[0].clone()
+    l0, _ = _step(m, x, ei, y, tokens, mask, 512)
+    l1, _ = _step(m, x, ei, y, tokens, mask, 512)                       # cached active set
+    assert torch.equal(l0, l1)
+    mask.copy_(masks[1])                                                 # in-place write: version counter moves
+    l2, _ = _step(m, x, ei, y, tokens, mask, 512)
+    r2, _ = _step(ref, x, ei, y, tokens, masks[1], 512)
+    assert torch.equal(l2, r2) and torch.equal(m.active_index, masks[1].nonzero(as_tuple=True)[0])
+    l3, _ = _step(m, x, ei, y, tokens, masks[2], 512)                    # another tensor
+    r3, _ = _step(ref, x, ei, y, tokens, masks[2], 512)
+    assert torch.equal(l3, r3)
