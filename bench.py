@@ -91,6 +91,7 @@ def build_model(args, data, dev):
                              plm_max_length=args.max_len, compute_dtype=cd,
                              plm_gradient_checkpointing=recompute_flags(args)[1],    # reference: ON (main.py:217-218)
                              activation_checkpointing=recompute_flags(args)[0])      # reference: ON (main.py:278-314)
+    m.overlap_streams = bool(getattr(args, "overlap_streams", False))
     return m.to(dev).train()
 
 
@@ -525,6 +526,7 @@ def main():
     ap.add_argument("--cpu-plm-sample", type=int, default=64)
     ap.add_argument("--cpu-hc", type=int, default=768)
     ap.add_argument("--no-encoder-graph", action="store_true", help="with hipGraphs: leave the text encoder eager (GNN + head regions only)")
+    ap.add_argument("--overlap-streams", action="store_true", help="text encoder on a second HIP stream beside the GNN (model.overlap_streams)")
     ap.add_argument("--no-whole-step-graph", action="store_true", help="with hipGraphs: three separate regions instead of ONE graph with the encoder and GNN branches side by side")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile the timed steps (host side) and write the top entries to FILE")
     ap.add_argument("--no-kernel-timers", action="store_true")

@@ -144,6 +144,11 @@ class GraphTextLM(nn.Module):
         self._graphs = GraphCache(capacity=4)
         self._tokens = {}
         self.dist = None          # gmlm_amd.dist.PartitionContext for the 1-D node partition (None = single GPU)
+        # run the text encoder on a second HIP stream beside the GNN (single GPU, eager path); results are identical, only
+        # the order in which independent kernels reach the device changes.  Opt-in: two streams of library GEMMs are a
+        # configuration the GEMM library is rarely run in ("streams")
+        self.overlap_streams = False
+        self._side_stream = None
         self._branch_stream = None  # side stream for the second cross-attention while a whole-step hipGraph is recorded (graphs.py)
         self._active_seen = None  # host copy / index tables of the last active-node mask TENSOR (reused while it is not written to)
         self._graphed = None      # gmlm_amd.graphs.GraphedStep: hipGraph recording of the GNN + head regions (capture_hip_graphs)
@@ -434,6 +439,24 @@ class GraphTextLM(nn.Module):
                 key, args, _ = self._bucket_tables(tokens, seen, self._cd())
                 return g.step(self, key, tokens, gnn_input_features, args)
             mask_copy = (seen["mask_h"], None)                        # already on the host
+        if self.overlap_streams and not replay and self.dist is None and gnn_input_features.is_cuda:
+            # GNN and text encoder are independent until the head: the encoder goes to a second HIP stream, so the GNN's
+            # HBM-bound kernels (basis composition, GraphNorm, aggregation) run BESIDE the encoder's GEMMs instead of before
+            # them; autograd replays every backward node on its forward stream, so the backward overlaps the same way.  The
+            # side stream is issued last: its backward is then queued first (the long one), the GNN's next to it.
+            cur = torch.cuda.current_stream()
+            side = self._second_stream(gnn_input_features.device)
+            side.wait_stream(cur)                                     # fork
+            gnn_embeds = self.get_graph_embeddings(gnn_input_features, edge_index, edge_type)
+            tokens = self.tokenize(all_node_texts)
+            with torch.cuda.stream(side):
+                weights = bert.prepare_weights(self.plm_encoder, self._cd())
+                plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)
+            cur.wait_stream(side)                                     # join
+            plm_embeds.record_stream(cur)                             # allocated on `side`, read (and saved for backward) on `cur`
+            if self.active_index is not None:
+                self.active_index.record_stream(cur)
+            return self.head(gnn_embeds, plm_embeds)
         # (a recorded encoder casts the weights inside its own graph)
         weights = None if (replay and g.encoder_enabled) else bert.prepare_weights(self.plm_encoder, self._cd())
         gnn_embeds = g.gnn(gnn_input_features) if replay else \
@@ -441,6 +464,11 @@ class GraphTextLM(nn.Module):
         tokens = self.tokenize(all_node_texts)
         plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, weights)   # fp32 [N, P]
         return g.head(gnn_embeds, plm_embeds) if replay else self.head(gnn_embeds, plm_embeds)
+
+    def _second_stream(self, device):
+        if self._side_stream is None or self._side_stream.device != device:
+            self._side_stream = torch.cuda.Stream(device=device)
+        return self._side_stream
 
     def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True,
                            whole_step: bool = True):

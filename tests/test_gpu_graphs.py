@@ -229,3 +229,34 @@ def test_mask_tensor_cache_notices_in_place_writes(dev):
     l3, _ = _step(m, x, ei, y, tokens, masks[2], 512)                    # another tensor
     r3, _ = _step(ref, x, ei, y, tokens, masks[2], 512)
     assert torch.equal(l3, r3)
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_stream_overlap_changes_nothing(dev, cd):
+    """``model.overlap_streams``: the text encoder on a second HIP stream beside the GNN (forward and, through autograd's
+    per-node streams, backward).  Same kernels, same inputs, same dropout seeds: logits and every gradient bit for bit,
+    with dropout on, over changing masks."""
+    import gmlm_amd
+    from test_gpu_model import hf_bert
+    from helpers import model_state_template
+    from param_recipe import recipe_state_dict
+    cfg = _cfg(0.3)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+
+    def make():
+        m = gmlm_amd.GraphTextLM(cfg["f_in"], cfg["hc"], cfg["c"], dropout_rate=0.3, plm_encoder=hf_bert(cfg["plm"]),
+                                 plm_max_length=12, compute_dtype=cd)
+        m.load_state_dict(recipe_state_dict(model_state_template(cfg["f_in"], cfg["hc"], cfg["c"], cfg["plm"]), cfg["seed"]))
+        return m.to(dev).train()
+
+    plain, over = make(), make()
+    over.overlap_streams = True
+    for mask in masks + masks:
+        torch.manual_seed(1234)                                          # dropout seeds come from torch's CPU generator
+        l0, g0 = _step(plain, x, ei, y, tokens, mask, 512)
+        torch.manual_seed(1234)
+        l1, g1 = _step(over, x, ei, y, tokens, mask, 512)
+        assert torch.equal(l0, l1)
+        assert set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
