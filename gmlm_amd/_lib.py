@@ -29,6 +29,8 @@ SIGNATURES = {
     "gmlm_gather_i64_to_i32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "gmlm_gather_i32": (C.c_int, [_p, _p, _i64, _p, _p]),
     "gmlm_segment_inv_count": (C.c_int, [_p, _i64, _p, _p]),
+    "gmlm_split_plan_capacity": (C.c_int, [_i64, _i64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "gmlm_split_plan_build": (C.c_int, [_p, _i64, _i64, _i64, _p, _p, _p, _p]),
     "gmlm_rgcn_mean_spmm": (C.c_int, [_p, _i64, _i64, _p, _p, _p, _i32, _i64, _i64, _p, _i64, _i32, _i64, _p, _p, _p, _i64, _i64,
                                       _p, _p]),
     "gmlm_basis_compose_fwd": (C.c_int, [_p, _p, _i32, _i32, _i64, _p, _p]),

@@ -193,6 +193,69 @@ extern "C" int gmlm_gather_i32(const int32_t* src, const int32_t* perm, int64_t 
   return GMLM_OK;
 }
 
+// Split plan for gmlm_rgcn_mean_spmm built ON THE DEVICE with capacity-sized arrays (no count ever reaches the host): ONE block;
+// every thread owns a contiguous range of segments, a block-wide exclusive scan of (long segments, chunks) per range gives its
+// output offsets, a second walk writes long_seg / chunk_ptr / chunk_owner in ascending segment order (deterministic); the unused
+// tail of every array is filled with -1 (chunk_ptr: the total), which the aggregation kernels skip.
+__global__ __launch_bounds__(1024) void split_plan_kernel(const int32_t* __restrict__ rowptr, int64_t nseg, int thresh, int cap_long,
+                                                           int cap_chunks, int32_t* __restrict__ long_seg, int32_t* __restrict__ chunk_ptr,
+                                                           int32_t* __restrict__ chunk_owner) {
+  __shared__ int s_long[1024], s_chunk[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (nseg + 1023) / 1024, s0 = tid * per, s1 = s0 + per < nseg ? s0 + per : nseg;
+  int nl = 0, nc = 0;
+  for (int64_t s = s0; s < s1; ++s) {
+    const int len = rowptr[s + 1] - rowptr[s];
+    if (len > thresh) { ++nl; nc += (len + thresh - 1) / thresh; }
+  }
+  s_long[tid] = nl; s_chunk[tid] = nc;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {                      // inclusive Hillis-Steele scan of both counters
+    const int a = tid >= off ? s_long[tid - off] : 0, b = tid >= off ? s_chunk[tid - off] : 0;
+    __syncthreads();
+    s_long[tid] += a; s_chunk[tid] += b;
+    __syncthreads();
+  }
+  int pl = s_long[tid] - nl, pc = s_chunk[tid] - nc;              // exclusive offsets of this thread's range
+  const int tot_l = s_long[1023], tot_c = s_chunk[1023];
+  for (int64_t s = s0; s < s1; ++s) {
+    const int len = rowptr[s + 1] - rowptr[s];
+    if (len > thresh) {
+      const int n = (len + thresh - 1) / thresh;
+      if (pl < cap_long && pc + n <= cap_chunks) {                // always true for capacities from gmlm_split_plan_capacity
+        long_seg[pl] = (int32_t)s;
+        chunk_ptr[pl] = pc;
+        for (int k = 0; k < n; ++k) chunk_owner[pc + k] = pl;
+      }
+      ++pl; pc += n;
+    }
+  }
+  for (int i = tot_l + tid; i < cap_long; i += 1024) long_seg[i] = -1;
+  for (int i = tot_l + tid; i <= cap_long; i += 1024) chunk_ptr[i] = tot_c;
+  for (int i = tot_c + tid; i < cap_chunks; i += 1024) chunk_owner[i] = -1;
+}
+
+extern "C" int gmlm_split_plan_capacity(int64_t num_items, int64_t long_threshold, int64_t* cap_long, int64_t* cap_chunks) {
+  GMLM_REQUIRE(num_items >= 0 && long_threshold > 0 && cap_long && cap_chunks, "split_plan_capacity: bad arguments");
+  *cap_long = num_items / long_threshold + 1;                    // segments longer than the threshold: < items / threshold
+  *cap_chunks = num_items / long_threshold + *cap_long;          // sum of ceil(len / threshold) over them
+  return GMLM_OK;
+}
+
+extern "C" int gmlm_split_plan_build(const int32_t* rowptr, int64_t num_segments, int64_t num_items, int64_t long_threshold,
+                                     int32_t* long_seg, int32_t* chunk_ptr, int32_t* chunk_owner, gmlm_stream_t stream) {
+  GMLM_REQUIRE(rowptr && long_seg && chunk_ptr && chunk_owner && num_segments > 0 && num_items >= 0 && long_threshold > 0 &&
+                   long_threshold < (1 << 30) && num_items < (1ll << 31),
+               "split_plan_build: bad arguments");
+  int64_t cl, cc;
+  gmlm_split_plan_capacity(num_items, long_threshold, &cl, &cc);
+  GMLM_REQUIRE(cl <= 65535, "split_plan_build: %ld possible long segments (> 65535): raise long_threshold", (long)cl);
+  split_plan_kernel<<<1, 1024, 0, as_stream(stream)>>>(rowptr, num_segments, (int)long_threshold, (int)cl, (int)cc, long_seg, chunk_ptr,
+                                                      chunk_owner);
+  GMLM_LAUNCH_CHECK();
+  return GMLM_OK;
+}
+
 extern "C" int gmlm_segment_inv_count(const int32_t* rowptr, int64_t num_segments, float* inv_cnt, gmlm_stream_t stream) {
   GMLM_REQUIRE(num_segments >= 0 && (num_segments == 0 || (rowptr && inv_cnt)), "segment_inv_count: bad arguments");
   if (num_segments == 0) return GMLM_OK;

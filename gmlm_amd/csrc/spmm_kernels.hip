@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void seg_reduce_vec_kernel(
       if (sp.thresh > 0 && end - beg > sp.thresh) continue;      // handled by the chunk + combine kernels
     } else {
       const int j = sp.chunk_owner[s];
+      if (j < 0) continue;                                         // unused slot of a capacity-sized plan (gmlm_split_plan_build)
       const int seg = sp.long_seg[j];
       beg = rowptr[seg] + (int)(s - sp.chunk_ptr[j]) * sp.thresh;
       end = rowptr[seg + 1];
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void seg_reduce_combine_kernel(const int32_t* 
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= f) return;
   const int seg = sp.long_seg[j];
+  if (seg < 0) return;                                             // unused slot of a capacity-sized plan
   float acc = 0.f;
   for (int k = sp.chunk_ptr[j]; k < sp.chunk_ptr[j + 1]; ++k) acc += sp.partial[(int64_t)k * f + c];
   const int len = rowptr[seg + 1] - rowptr[seg];

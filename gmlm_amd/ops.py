@@ -169,6 +169,22 @@ def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out, split=None):
           "gmlm_rgcn_mean_spmm")
 
 
+def device_split_plan(rowptr: torch.Tensor, num_items: int, thresh: int = 64):
+    """``graph.SplitPlan`` for segments known only on the device (they change every step): capacity-sized arrays filled by ONE
+    kernel, no host round trip; unused slots are -1 and skipped by the aggregation kernels (gmlm_split_plan_build)."""
+    import ctypes
+    from .graph import SplitPlan
+    cl, cc = ctypes.c_int64(), ctypes.c_int64()
+    check(lib().gmlm_split_plan_capacity(int(num_items), int(thresh), ctypes.byref(cl), ctypes.byref(cc)), "gmlm_split_plan_capacity")
+    dev = rowptr.device
+    long_seg = torch.empty(cl.value, dtype=torch.int32, device=dev)
+    chunk_ptr = torch.empty(cl.value + 1, dtype=torch.int32, device=dev)
+    chunk_owner = torch.empty(cc.value, dtype=torch.int32, device=dev)
+    check(lib().gmlm_split_plan_build(_ptr(rowptr), rowptr.numel() - 1, int(num_items), int(thresh), _ptr(long_seg), _ptr(chunk_ptr),
+                                      _ptr(chunk_owner), _stream()), "gmlm_split_plan_build")
+    return SplitPlan(int(thresh), long_seg, chunk_ptr, chunk_owner, int(cl.value), int(cc.value))
+
+
 class RGCNAggregate(torch.autograd.Function):
     """H[i, r*F:(r+1)*F] = mean_{j->i, type r} x[j]  (K2); backward = same kernel on the transposed CSR (K3)."""
 
@@ -657,10 +673,14 @@ class EmbedSum(torch.autograd.Function):
         # fp32.  The aggregation kernel keeps one storage dtype for source and result, so a bf16 gradient is widened once
         # ([T, P] fp32 transient: one pass, 1-2 % of the encoder backward) instead of rounding every sum to 8 bits.
         g32 = g if g.dtype == torch.float32 else g.float()
+        # Real text makes a few segments very long ([CLS] / [SEP] once per sequence, every position id once per sequence that is
+        # long enough, frequent words): segments of more than 64 rows are reduced chunk-wise through a split plan built on the
+        # device from this step's rowptr (one lane group walking a 1,257-row - or, at arxiv size, 40,000-row - segment alone was
+        # the whole duration of this kernel)
         for ids, nseg in ((tok, vocab), (pos_ids, npos)):
             _, perm, rowptr, _ = _segment_sort(ids, None, None, 1, nseg)
             acc = torch.empty(nseg, p, dtype=torch.float32, device=g.device)
-            _spmm(g32, rowptr, perm, None, False, nseg, p, acc)
+            _spmm(g32, rowptr, perm, None, False, nseg, p, acc, device_split_plan(rowptr, ids.numel()))
             grads.append(acc)
         d_type = torch.zeros(ntype, p, dtype=torch.float32, device=g.device)
         d_type[0] = grads[1].sum(0)

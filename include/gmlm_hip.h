@@ -98,8 +98,19 @@ int gmlm_segment_inv_count(const int32_t* rowptr, int64_t num_segments, float* i
  * many edges, each chunk is reduced by its own lane group into `partial` (fp32 [n_chunks, f]) and a third
  * kernel adds the partials of a segment in chunk order (still deterministic).  The plan arrays
  * (`long_seg` [n_long], `chunk_ptr` [n_long+1], `chunk_owner` [n_chunks]) are index data built once per
- * graph by the caller; pass long_threshold = 0 / n_long = 0 for no splitting.
+ * graph by the caller (or on the device: gmlm_split_plan_build, entries of -1 = unused slot); pass long_threshold = 0 /
+ * n_long = 0 for no splitting.
  * ------------------------------------------------------------------------------------------- */
+/* Split plan built on the device, for segment sets that change every step (the embedding-gradient segment sums: token /
+ * position ids of the step's batch; replaces the scatter-add of hf BertEmbeddings' backward).  Arrays have CAPACITY size -
+ * long_seg [cap_long], chunk_ptr [cap_long + 1], chunk_owner [cap_chunks], partial [cap_chunks, f] - from
+ * gmlm_split_plan_capacity(num_items = rowptr[num_segments], long_threshold); unused slots hold -1 and are skipped by
+ * gmlm_rgcn_mean_spmm, which is then called with n_long = cap_long, n_chunks = cap_chunks.  One launch, no host round trip,
+ * deterministic. */
+int gmlm_split_plan_capacity(int64_t num_items, int64_t long_threshold, int64_t* cap_long, int64_t* cap_chunks);
+int gmlm_split_plan_build(const int32_t* rowptr, int64_t num_segments, int64_t num_items, int64_t long_threshold,
+                          int32_t* long_seg, int32_t* chunk_ptr, int32_t* chunk_owner, gmlm_stream_t stream);
+
 int gmlm_rgcn_mean_spmm(const void* src, int64_t src_rows, int64_t src_stride, const int32_t* rowptr,
                         const int32_t* idx, const float* edge_w, int mean, int64_t num_segments, int64_t f,
                         void* out, int64_t out_stride, int dtype, int64_t long_threshold, const int32_t* long_seg,

@@ -718,3 +718,48 @@ def test_embed_sum_matches_torch_gathers(dev, dtype):
         ops.check_embed_ids(tok.view(1, -1), torch.tensor([npos + 1], device=dev), vocab, npos)
     ops.check_embed_ids(tok.view(1, -1), torch.tensor([npos], device=dev), vocab, npos)
     assert float(gt[1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", ["mixed", "none_long", "one_segment", "exactly_thresh", "many_long"])
+def test_device_split_plan_matches_host_plan(dev, case):
+    """gmlm_split_plan_build (one kernel, capacity-sized arrays, -1 in unused slots) against the host-built plan of
+    graph.make_split_plan (its counts go through the host): same long segments in ascending order, same chunk table; and the
+    chunked segment sum it drives equals the unsplit one up to fp32 summation order and is bit-deterministic."""
+    from gmlm_amd import ops
+    from gmlm_amd.graph import make_split_plan, _segment_sort
+    g = torch.Generator().manual_seed({"mixed": 1, "none_long": 2, "one_segment": 3, "exactly_thresh": 4, "many_long": 5}[case])
+    thresh, nseg, f = 64, 3001, 256
+    if case == "mixed":
+        ids = torch.randint(0, nseg, (20000,), generator=g)
+        ids[:5000] = 11; ids[5000:5100] = 2999; ids[5100:5165] = 0
+    elif case == "none_long":
+        ids = torch.randint(0, nseg, (4000,), generator=g)
+    elif case == "one_segment":
+        ids = torch.full((7777,), 1234)
+    elif case == "exactly_thresh":
+        ids = torch.cat([torch.full((64,), 5), torch.full((65,), 6), torch.full((128,), 7), torch.full((129,), 8)])
+    else:
+        ids = torch.randint(0, 40, (30000,), generator=g)            # every segment ~750 rows
+    ids = ids.to(dev)
+    _, perm, rowptr, _ = _segment_sort(ids, None, None, 1, nseg)
+    plan = ops.device_split_plan(rowptr, ids.numel(), thresh)
+    host = make_split_plan(rowptr, thresh)
+    nl = 0 if host is None else host.n_long
+    nc = 0 if host is None else host.n_chunks
+    assert plan.n_long >= nl + 0 and plan.n_chunks >= nc
+    assert bool((plan.long_seg[nl:] == -1).all()) and bool((plan.chunk_owner[nc:] == -1).all())
+    assert bool((plan.chunk_ptr[nl:] == nc).all())
+    if host is not None:
+        assert torch.equal(plan.long_seg[:nl], host.long_seg) and torch.equal(plan.chunk_ptr[:nl + 1], host.chunk_ptr)
+        assert torch.equal(plan.chunk_owner[:nc], host.chunk_owner)
+    src = torch.randn(ids.numel(), f, generator=g).to(dev)
+    a = torch.empty(nseg, f, device=dev)
+    b = torch.empty(nseg, f, device=dev)
+    c = torch.empty(nseg, f, device=dev)
+    ops._spmm(src, rowptr, perm, None, False, nseg, f, a, plan)
+    ops._spmm(src, rowptr, perm, None, False, nseg, f, b, ops.device_split_plan(rowptr, ids.numel(), thresh))
+    ops._spmm(src, rowptr, perm, None, False, nseg, f, c)
+    ref = torch.zeros(nseg, f, device=dev, dtype=torch.float64).index_add_(0, ids, src.double())
+    assert torch.equal(a, b)
+    assert float((a.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+    assert float((c.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
