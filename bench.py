@@ -277,6 +277,7 @@ def _micro_spmm(dev, args, out):
 def _micro_attn(dev, args, out):
     from gmlm_amd import ops
     for tag, b, h, l, d, masked in (("mha_L512", 32, 12, 512, 64, True), ("mha_L128", 256, 12, 128, 64, True),
+                                    ("mha_L2048", 16, 12, 2048, 64, True),
                                     ("xattn_N5201", 1, 8, 5201, 96, False), ("xattn_N20804", 1, 8, 20804, 96, False)):
         q, k, v = (torch.randn(b, l, h * d, device=dev, dtype=torch.bfloat16, requires_grad=True) for _ in range(3))
         kv_len = torch.randint(l // 2, l + 1, (b,), device=dev, dtype=torch.int32) if masked else None
@@ -753,6 +754,14 @@ def main():
                                    "achieved_executed": mh.get("fwd_TFLOPs_executed"), "avg_launch_ms": mh["fwd_ms"],
                                    "note": "100 MB of q/k/v/o for 18 GF executed: this shape sits at the HBM/MFMA ridge (257 flop/B vs 312)",
                                    "pmc": _pmc_attn("attn_fwd_pipe_kernel<64, 4", 4 * 384 * 256)}}
+            ml = mi.get("mha_L2048")
+            if ml:
+                # the same kernel where masked attention at h = 768 is MFMA-bound: L / 2 = 1,024 flop per byte of q/k/v/o
+                out["attention"]["masked_mha_fwd_L2048"] = {
+                    "kernel": "attn_fwd_pipe_kernel<64, 4> (B=16, h=12, L=2048, d=64, kv_len ~ U[1024,2048])",
+                    "achieved_padded": ml["fwd_TFLOPs"], "frac_padded": ml["fwd_frac_mfma_peak"],
+                    "achieved_executed": ml.get("fwd_TFLOPs_executed"), "avg_launch_ms": ml["fwd_ms"],
+                    "pmc": _pmc_attn("attn_fwd_pipe_kernel<64, 4", 16 * 12 * 16 * 256)}
     if rank == 0 and world == 1 and not args.no_fp32_leg and args.dtype == "bf16" and args.workload == "squirrel":
         # the same step with fp32 operands (the dtype the 1e-4 parity bar is stated in)
         args32 = argparse.Namespace(**{**vars(args), "dtype": "f32"})

@@ -82,9 +82,13 @@ def test_cross_attention_geometry_8wave_kernels_vs_dense_fp64(dev, p_drop):
         assert abs(keep - (1 - round(p_drop * 256) / 256)) < 2e-3
 
 
-def test_masked_mha_L512_d64_vs_dense_fp64(dev):
+@pytest.mark.parametrize("b,l", [(32, 512), (2, 2048)])
+def test_masked_mha_d64_vs_dense_fp64(dev, b, l):
+    """B = 32 / L = 512 is the shape of ``attention.masked_mha_fwd`` (HBM side of the ridge); L = 2,048 the geometry of
+    ``attention.masked_mha_fwd_L2048`` (the MFMA-bound regime of the same kernels; the bench runs it at B = 16, here B = 2 keeps
+    the dense fp64 reference small - the kernels treat (batch, head) pairs independently)."""
     from gmlm_amd import ops
-    b, h, l, d = 32, 12, 512, 64
+    h, d = 12, 64
     g = torch.Generator().manual_seed(64)
     q, k, v, go = (torch.randn(b, l, h * d, generator=g).to(dev, torch.bfloat16) for _ in range(4))
     kv_len = torch.randint(l // 2, l + 1, (b,), generator=g).to(dev, torch.int32)

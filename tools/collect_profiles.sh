@@ -20,8 +20,8 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/${TAG}_pmc_sfetch -o f --output-
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/${TAG}_pmc_swrite -o w --output-format csv -- python3 $R/bench.py $B > $O/${TAG}_pmc_swrite.log 2>&1
 echo "traffic done"
 # 3. MFMA / issue counters of the attention kernels: CrossAttention geometry at N = 20,804 and N = 5,201, masked MHA L = 512, the
-#    in-step packed short-sequence mix
-for c in =xattn_N20804 =xattn_N5201 =mha_L512 packed_mix; do
+#    in-step packed short-sequence mix; masked MHA at L = 2,048 (the MFMA-bound regime of the d = 64 kernel)
+for c in =xattn_N20804 =xattn_N5201 =mha_L512 =mha_L2048_masked packed_mix; do
   rocprofv3 -i $R/tools/ubench/pmc_attn_in.txt --kernel-trace -d $O/${TAG}_pmc_attn/$c -o pmc --output-format csv -- $R/tools/ubench/attn_bench 1 1 0 $c > $O/${TAG}_pmc_attn_$c.log 2>&1
 done
 cd $R

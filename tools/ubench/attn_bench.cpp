@@ -43,7 +43,8 @@ int main(int argc, char** argv) {
                         {"mha_L512_drop", 32, 12, 512, 64, true, 0.1f}, {"mha_L77_odd", 64, 12, 77, 64, true, 0.f},
                         {"xattn_N999", 1, 8, 999, 96, false, 0.f},
                         {"mha_L512_b8", 8, 12, 512, 64, true, 0.f}, {"mha_L512_b128", 128, 12, 512, 64, true, 0.f},
-                        {"mha_L512_full", 32, 12, 512, 64, false, 0.f}, {"mha_L2048", 8, 12, 2048, 64, false, 0.f}};
+                        {"mha_L512_full", 32, 12, 512, 64, false, 0.f}, {"mha_L2048", 8, 12, 2048, 64, false, 0.f},
+                        {"mha_L2048_masked", 16, 12, 2048, 64, true, 0.f}, {"mha_L4096_masked", 8, 12, 4096, 64, true, 0.f}};
   std::mt19937 rng(1234);
   std::normal_distribution<float> nd(0.f, 1.f);
   for (const Case& c : cases) {
