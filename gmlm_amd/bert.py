@@ -182,7 +182,7 @@ class _Linear(torch.autograd.Function):
                 if need[i]:
                     grads[i] = g if g.dtype == m.dtype else g.to(m.dtype)
         if ctx.has_bias and any(need[n_w:]):
-            db = dy2.sum(0, dtype=torch.float32)
+            db = ops.column_sum(dy2) if dy2.is_cuda and dy2.dtype in (torch.float32, torch.bfloat16) else dy2.sum(0, dtype=torch.float32)
             for i, (m, g) in enumerate(zip(masters[n_w:], db.split([m.shape[0] for m in masters[n_w:]], 0))):
                 if need[n_w + i]:
                     grads[n_w + i] = g if g.dtype == m.dtype else g.to(m.dtype)

@@ -62,6 +62,24 @@ def _linear(x, weight, bias=None):
         return F.linear(x, w, b)
 
 
+class _SelectRows(torch.autograd.Function):
+    """x[idx] for UNIQUE row indices (the relations that occur): the backward is a plain row copy into zeros, not the
+    atomicAdd scatter of ``index_select``'s backward (unique rows need no accumulation; no atomics = bitwise reproducible)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.save_for_backward(idx)
+        ctx.rows = x.shape[0]
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        out = g.new_zeros((ctx.rows,) + tuple(g.shape[1:]))
+        out.index_copy_(0, idx, g)
+        return out, None
+
+
 class _BasisCompose(torch.autograd.Function):
     """W_r = sum_b comp[r, b] * weight[b] for the relations that occur (K10, one streaming pass over the
     bases).  In the node-partitioned run the gradient of the (R_a x in*out) composed weights is all-reduced
@@ -130,7 +148,7 @@ class RGCNConv(nn.Module):
         """[R_a * (in + pad), out]: W_r = sum_b comp[r, b] weight[b] for the relations that occur.
         ``reducer`` (node-partitioned run): all-reduces d(W_r); ``weight``/``comp`` gradients then come out
         already summed over ranks and are flagged so the bucketed gradient all-reduce skips them."""
-        comp = self.comp.index_select(0, csr.active_index)                   # [R_a, B]
+        comp = _SelectRows.apply(self.comp, csr.active_index)                # [R_a, B]
         w = _BasisCompose.apply(comp, self.weight.view(self.num_bases, -1), reducer)
         self.weight._gmlm_grad_reduced = self.comp._gmlm_grad_reduced = reducer is not None
         w = w.view(len(csr.active_relations), self.in_channels, self.out_channels)

@@ -169,6 +169,22 @@ def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out, split=None):
           "gmlm_rgcn_mean_spmm")
 
 
+def column_sum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 column sums of a 2-D fp32 / bf16 tensor on the K4 statistics kernel (fixed-order partials, deterministic): the bias
+    gradients of the dense layers.  (``x.sum(0, dtype=float32)`` - ATen's reduction with its semaphore buffer - gave wrong sums
+    from the fourth replay on inside one recorded hipGraph, tests/test_gpu_graphs.py; this kernel needs no zero-initialised
+    scratch.)"""
+    _cuda(x)
+    x = x.contiguous()
+    n, f = x.shape
+    out = torch.empty(2, f, dtype=torch.float32, device=x.device)
+    if n == 0:
+        return out[0].zero_()
+    ws = _ws(lib().gmlm_colstats_workspace_bytes(n, f), x.device)
+    check(lib().gmlm_colstats(_ptr(x), _dt(x), None, n, f, _ptr(out[0]), _ptr(out[1]), _ptr(ws), ws.numel(), _stream()), "gmlm_colstats")
+    return out[0]
+
+
 def device_split_plan(rowptr: torch.Tensor, num_items: int, thresh: int = 64):
     """``graph.SplitPlan`` for segments known only on the device (they change every step): capacity-sized arrays filled by ONE
     kernel, no host round trip; unused slots are -1 and skipped by the aggregation kernels (gmlm_split_plan_build)."""
@@ -518,7 +534,7 @@ class AttentionQKV(torch.autograd.Function):
         dbs = ()
         if want_db:
             if db is None:
-                db = dqkv.reshape(-1, hd3).sum(0, dtype=torch.float32)
+                db = column_sum(dqkv.reshape(-1, hd3))
             dbs = tuple(g if g.dtype == dt_ else g.to(dt_)
                         for g, (_, dt_) in zip(db.split([n_ for n_, _ in ctx.bias_shapes], 0), ctx.bias_shapes))
         return (dqkv, None, None, None, None, None, None, None, None, None, *dbs)
