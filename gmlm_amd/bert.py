@@ -20,7 +20,7 @@ import torch
 from torch.utils.checkpoint import checkpoint
 
 from . import ops
-from .nn import _linear, attention_any_dim
+from .nn import _Linear, _linear, _mm, _splitk_wgrad, attention_any_dim  # noqa: F401  (dense-layer functions live in nn.py)
 
 
 def check_supported(plm) -> None:
@@ -104,94 +104,6 @@ def prepare_weights(plm, cd):
         if dsts:
             torch._foreach_copy_(dsts, srcs)
     return out
-
-
-_F32_OUT = [True]          # torch.bmm(..., out_dtype=float32) available (checked on first use)
-
-
-def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor, keep_fp32: bool = False) -> torch.Tensor:
-    """dW [N, K] = dy2^T [N, T] @ x2 [T, K] (returned in fp32 when ``keep_fp32``, else in dy2's dtype).  The reduction dim is the token count (10^4..10^5) while the
-    output is only a few 256x256 tiles, so one hipBLASLt call leaves most CUs idle; cutting T into S
-    slices (batched GEMM, fp32 partials) and adding them fills the chip (measured 1.5-2.7x on MI355X)."""
-    t, n = dy2.shape
-    k = x2.shape[1]
-    tiles = ((n + 255) // 256) * ((k + 255) // 256)
-    s = 1
-    if tiles < 128 and t >= 4096:
-        import math
-        # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
-        s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
-    if s == 1:
-        dw = dy2.t() @ x2
-        return dw.float() if keep_fp32 else dw
-    # a packed batch has an arbitrary token count: S equal slices of floor(T/S) rows + a tail of < S rows
-    q = t // s
-    a = dy2[:s * q].view(s, q, n).transpose(1, 2)
-    b = x2[:s * q].view(s, q, k)
-    if _F32_OUT[0] and dy2.dtype != torch.float32:
-        try:
-            dw = torch.bmm(a, b, out_dtype=torch.float32).sum(0)
-        except (RuntimeError, TypeError):
-            _F32_OUT[0] = False
-            dw = torch.bmm(a, b).float().sum(0)
-    else:
-        dw = torch.bmm(a, b).float().sum(0)
-    if s * q < t:
-        dw += dy2[s * q:].t() @ x2[s * q:]         # < S rows: one tiny GEMM, added in fp32
-    return dw if keep_fp32 else dw.to(dy2.dtype)
-
-
-class _Linear(torch.autograd.Function):
-    """y = x @ wc^T (+ bc) on hipBLASLt with the cached compute-dtype operands ``wc`` / ``bc``; the gradients go
-    to the fp32 MASTER parameters (``masters`` = the weight(s) whose rows stack up to ``wc``, then the bias(es)
-    stacking up to ``bc``): split-K weight gradient and the bias column sum stay in fp32 end to end.
-    With ``residual`` the input is also returned as a second output for the residual branch, so that the two
-    gradients of ``x`` meet HERE and the data-gradient GEMM accumulates onto the residual one (beta = 1 in the
-    GEMM epilogue) instead of autograd running a separate add kernel."""
-
-    @staticmethod
-    def forward(ctx, x, wc, bc, residual, bias_grad, *masters):
-        """``bias_grad`` False: ``bc`` is added but its masters are not among ``masters`` (their gradient is produced
-        elsewhere: ops.AttentionQKV returns the fused QKV bias gradient itself, from inside its backward kernel)."""
-        ctx.save_for_backward(x, wc)
-        ctx.masters = masters
-        ctx.has_bias = bc is not None and bias_grad
-        ctx.n_w = len(masters) // 2 if ctx.has_bias else len(masters)
-        y = torch.nn.functional.linear(x, wc, bc)
-        return (y, x.view_as(x)) if residual else y
-
-    @staticmethod
-    def backward(ctx, dy, dxres=None):
-        x, wc = ctx.saved_tensors
-        masters, n_w = ctx.masters, ctx.n_w
-        dy2 = dy.reshape(-1, dy.shape[-1])
-        x2 = x.reshape(-1, x.shape[-1])
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if dxres is None:
-                dx = (dy2 @ wc).view(x.shape)
-            else:
-                # the residual gradient buffer is ours alone (it was produced for this node): accumulate in place
-                dres2 = dxres.reshape(-1, x.shape[-1])
-                dx = (dres2.addmm_(dy2, wc) if dres2.is_contiguous() else torch.addmm(dres2, dy2, wc)).view(x.shape)
-        grads = [None] * len(masters)
-        need = ctx.needs_input_grad[5:]
-        if any(need[:n_w]):
-            dw = _splitk_wgrad(dy2, x2, keep_fp32=True)
-            for i, (m, g) in enumerate(zip(masters[:n_w], dw.split([m.shape[0] for m in masters[:n_w]], 0))):
-                if need[i]:
-                    grads[i] = g if g.dtype == m.dtype else g.to(m.dtype)
-        if ctx.has_bias and any(need[n_w:]):
-            db = ops.column_sum(dy2) if dy2.is_cuda and dy2.dtype in (torch.float32, torch.bfloat16) else dy2.sum(0, dtype=torch.float32)
-            for i, (m, g) in enumerate(zip(masters[n_w:], db.split([m.shape[0] for m in masters[n_w:]], 0))):
-                if need[n_w + i]:
-                    grads[n_w + i] = g if g.dtype == m.dtype else g.to(m.dtype)
-        return (dx, None, None, None, None, *grads)
-
-
-def _mm(x, wc, bc, masters, residual=False, bias_grad=True):
-    with torch.autocast("cuda", enabled=False):
-        return _Linear.apply(x, wc, bc, residual, bias_grad, *masters)
 
 
 def _layer(lw, h, lens, heads, training, p_hidden, p_attn, eps, cu=None, max_len=0, pair_count=None, groups=None):

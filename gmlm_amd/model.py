@@ -22,7 +22,8 @@ from torch.utils.checkpoint import checkpoint
 
 from . import bert, ops
 from .graph import GraphCache, RelCSR
-from .nn import CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, compute_dtype
+from .nn import (CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, compute_dtype, cross_attention_specs, linear_specs,
+                 shadow_params, use_shadow)
 
 logger = logging.getLogger(__name__)
 
@@ -149,6 +150,7 @@ class GraphTextLM(nn.Module):
         # configuration the GEMM library is rarely run in ("streams")
         self.overlap_streams = False
         self._side_stream = None
+        self._gnn_shadow = None   # nn.ParamShadow of the last get_graph_embeddings call (compute-dtype operands of its dense layers)
         self._branch_stream = None  # side stream for the second cross-attention while a whole-step hipGraph is recorded (graphs.py)
         self._active_seen = None  # host copy / index tables of the last active-node mask TENSOR (reused while it is not written to)
         self._graphed = None      # gmlm_amd.graphs.GraphedStep: hipGraph recording of the GNN + head regions (capture_hip_graphs)
@@ -173,8 +175,9 @@ class GraphTextLM(nn.Module):
         conv, norm, drop = getattr(self, f"rgcn{k}"), getattr(self, f"gnorm{k}"), getattr(self, f"dropout{k}")
         if self.dist is not None:
             x = self.dist.with_halo(x, defer=True)                    # [n_local + n_halo, F]; halo rows land under the root GEMM
-        z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None,
-                             self.dist.halo_ready if self.dist is not None else None)                # [n, out] in cd
+        with use_shadow(self._gnn_shadow):                            # (no-op inside get_graph_embeddings; a checkpoint recompute needs it)
+            z = conv.forward_csr(x, csr, self.dist.all_reduce_sum if self.dist is not None else None,
+                                 self.dist.halo_ready if self.dist is not None else None)            # [n, out] in cd
         cd = x.dtype
         n_total = self.dist.n_total if self.dist is not None else z.size(0)
         if n_total > 1:                                               # main.py:273 guard
@@ -198,11 +201,23 @@ class GraphTextLM(nn.Module):
         run = (lambda k, x: checkpoint(self._block, k, x, csr, use_reentrant=False)) \
             if (self.activation_checkpointing and self.training and torch.is_grad_enabled()) else \
             (lambda k, x: self._block(k, x, csr))
+        # compute-dtype operands of this region's dense layers: one flat buffer, one multi-tensor copy (nn.ParamShadow); kept on
+        # the module so that a checkpoint recompute of a block (which runs in backward, outside this call) finds the same operands
+        specs = linear_specs(self.residual_proj1, self.residual_proj2)
+        for k in (1, 2, 3, 4):
+            conv = getattr(self, f"rgcn{k}")
+            specs += [(id(conv.root), [conv.root], x0.shape[1] - f_in if k == 1 else 0), (id(conv.bias), [conv.bias], 0)]
+        with shadow_params(specs, cd, x0.device) as sh:
+            self._gnn_shadow = sh
+            return self._graph_embeddings_body(x0, f_in, cd, run)
+
+    def _graph_embeddings_body(self, x0, f_in, cd, run):
         e1 = run(1, x0)
-        x1 = (e1.float() + _linear(x0[:, :f_in] if x0.shape[1] != f_in else x0, self.residual_proj1.weight,
-                                   self.residual_proj1.bias).float()).to(cd)
+        # (a sum of two compute-dtype tensors is formed in fp32 and rounded once - the same value as adding their fp32 copies
+        # and casting, without the three cast passes)
+        x1 = e1 + _linear(x0[:, :f_in] if x0.shape[1] != f_in else x0, self.residual_proj1.weight, self.residual_proj1.bias)
         e2 = run(2, x1)
-        x2 = (e2.float() + _linear(x1, self.residual_proj2.weight, self.residual_proj2.bias).float()).to(cd)
+        x2 = e2 + _linear(x1, self.residual_proj2.weight, self.residual_proj2.bias)
         e3 = run(3, x2)
         e4 = run(4, e3)
         # main.py:317-318 computes x4 + residual_proj3(x2) and discards it: skipped (no effect on outputs or grads)
@@ -484,6 +499,13 @@ class GraphTextLM(nn.Module):
     def head(self, gnn_embeds, plm_embeds):
         """main.py:360-372."""
         cd = self._cd()
+        fn, c = self.fusion_network, self.classifier
+        specs = (cross_attention_specs(self.graph_to_text_attn) + cross_attention_specs(self.text_to_graph_attn)
+                 + linear_specs(c[3]) + [(id(fn[0].weight), [fn[0].weight], 0), (id(c[0].weight), [c[0].weight], 0)])
+        with shadow_params(specs, cd, gnn_embeds.device):
+            return self._head_body(gnn_embeds, plm_embeds, cd)
+
+    def _head_body(self, gnn_embeds, plm_embeds, cd):
         g = gnn_embeds.unsqueeze(0)
         t = plm_embeds.unsqueeze(0)
         ring = self.dist.ring_attention if (self.dist is not None and self.dist.use_ring) else None
@@ -509,9 +531,9 @@ class GraphTextLM(nn.Module):
         else:
             text_attended = self.text_to_graph_attn(t, g, gather, ring)
         fn = self.fusion_network
-        pdim = gnn_attended.shape[-1]
-        w = fn[0].weight
-        fused = _linear(gnn_attended, w[:, :pdim]) + _linear(text_attended, w[:, pdim:])        # cat-free Linear(2P -> P)
+        # Linear(2P -> P) over [gnn_attended | text_attended] (main.py:366-367): one concatenation of the two [N, P] activations,
+        # ONE GEMM with K = 2P (one rounding of the sum; two half GEMMs + an add rounded three times)
+        fused = _linear(torch.cat([gnn_attended, text_attended], -1), fn[0].weight)
         fused = ops.bias_res_layernorm(fused, fn[0].bias, None, fn[1].weight, fn[1].bias, fn[1].eps, True, fn[3].p,
                                        self.training)
         fused = fused.squeeze(0)

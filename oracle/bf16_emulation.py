@@ -8,8 +8,9 @@ fp32 on the CPU, but rounds to bf16 at every point where the bf16 HIP path holds
   * every operand of a GEMM and of the attention products (Q, K, V, dO; the probabilities P before P.V; dS before dS.K
     and dS^T.Q), products and sums in fp32;
   * every activation and every activation-gradient the path STORES between two kernels;
-  * parameters are fp32 masters, rounded where they enter a GEMM; weight gradients of the text encoder's linears stay
-    fp32 (split-K fp32 partials), the other linears' weight / bias gradients are rounded once (GEMM output in bf16).
+  * parameters are fp32 masters, rounded where they enter a GEMM; weight / bias gradients of every dense layer stay fp32
+    (fp32 GEMM outputs / split-K fp32 partials / fixed-order fp32 column sums straight to the masters); the RGCN relation
+    weights' gradient is a bf16 GEMM output (it feeds the basis-composition backward).
 
 It does NOT call, import or share code with ``gmlm_amd``; it follows the order of operations that DESIGN.md sections 3-4
 document for the kernels (K2-K10), including the kernel-specific details that decide which values get rounded:
@@ -116,7 +117,7 @@ def _rgcn_block(conv, norm, x, edge_index, edge_type, rels):
     if pad:
         w_rel = F.pad(w_rel, (0, 0, 0, pad))
         root = F.pad(root, (0, 0, 0, pad))
-    out1 = lin(x, root.t(), conv.bias)                                    # addmm(bias, x, root) -> bf16
+    out1 = lin(x, root.t(), conv.bias, round_wgrad=False)                 # addmm(bias, x, root) -> bf16; root / bias gradients fp32 (nn._RootAddmm)
     h = _aggregate(x, edge_index, edge_type, rels)
     z = st(out1 + lin_noround(h, w_rel.reshape(-1, conv.out_channels).t()))   # out.addmm_(h, w): one rounding of the sum
     if z.shape[0] > 1:
@@ -184,9 +185,9 @@ def graph_embeddings(om, x0, edge_index, edge_type):
     rels = sorted(set(edge_type.tolist())) or [0]
     f_in = om.rgcn1.in_channels
     e1 = _rgcn_block(om.rgcn1, om.gnorm1, x0, edge_index, edge_type, rels)
-    x1 = st(e1 + lin(x0[:, :f_in], om.residual_proj1.weight, om.residual_proj1.bias))
+    x1 = st(e1 + lin(x0[:, :f_in], om.residual_proj1.weight, om.residual_proj1.bias, round_wgrad=False))
     e2 = _rgcn_block(om.rgcn2, om.gnorm2, x1, edge_index, edge_type, rels)
-    x2 = st(e2 + lin(x1, om.residual_proj2.weight, om.residual_proj2.bias))
+    x2 = st(e2 + lin(x1, om.residual_proj2.weight, om.residual_proj2.bias, round_wgrad=False))
     e3 = _rgcn_block(om.rgcn3, om.gnorm3, x2, edge_index, edge_type, rels)
     e4 = _rgcn_block(om.rgcn4, om.gnorm4, e3, edge_index, edge_type, rels)
     m = om.multi_scale_fusion
@@ -330,12 +331,13 @@ def cross_attention(mod, x, y, num_heads=8):
     """main.py:151-165 on the bf16 path: fused K|V projection, streaming attention, out projection."""
     n, cdim = x.shape
     xq, yk = st(x), st(y)                                                      # .to(bf16) of the fp32 embeddings
-    q = lin(xq, mod.q_proj.weight, mod.q_proj.bias)
-    kv = lin(yk, torch.cat([mod.k_proj.weight, mod.v_proj.weight], 0), torch.cat([mod.k_proj.bias, mod.v_proj.bias], 0))
+    q = lin(xq, mod.q_proj.weight, mod.q_proj.bias, round_wgrad=False)
+    kv = lin(yk, torch.cat([mod.k_proj.weight, mod.v_proj.weight], 0), torch.cat([mod.k_proj.bias, mod.v_proj.bias], 0),
+             round_wgrad=False)
     d = cdim // num_heads
     o = _LongAttention.apply(_heads(q, num_heads), _heads(kv[:, :cdim], num_heads), _heads(kv[:, cdim:], num_heads), d ** -0.5)
     o = o.transpose(0, 1).reshape(n, cdim)
-    return lin(o, mod.out_proj.weight, mod.out_proj.bias)
+    return lin(o, mod.out_proj.weight, mod.out_proj.bias, round_wgrad=False)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -433,10 +435,10 @@ def forward(om: "O.OracleGraphTextLM", x, edge_index, input_ids, attention_mask,
     t_att = cross_attention(om.text_to_graph_attn, plm, gnn)
     fn, cl = om.fusion_network, om.classifier
     p = g_att.shape[-1]
-    fused = st(lin(g_att, fn[0].weight[:, :p]) + lin(t_att, fn[0].weight[:, p:]))
+    fused = lin(torch.cat([g_att, t_att], -1), fn[0].weight, round_wgrad=False)   # ONE GEMM over [g | t], K = 2P
     fused = st(F.gelu(F.layer_norm(fused + fn[0].bias, (p,), fn[1].weight, fn[1].bias, fn[1].eps)))
-    hcls = st(F.gelu(lin(fused, cl[0].weight) + cl[0].bias))
-    logits = lin(hcls, cl[3].weight, cl[3].bias)
+    hcls = st(F.gelu(lin(fused, cl[0].weight, round_wgrad=False) + cl[0].bias))
+    logits = lin(hcls, cl[3].weight, cl[3].bias, round_wgrad=False)
     if return_parts:
         return logits, dict(gnn_embeds=gnn, plm_embeds=plm, gnn_attended=g_att, text_attended=t_att)
     return logits
