@@ -535,6 +535,56 @@ class _ScaledProjectionSum(torch.autograd.Function):
         return (d_weights, None, *d_embs, *d_ws, *d_bs)
 
 
+class _ScaledProjectionCat(torch.autograd.Function):
+    """The same sum as ONE GEMM: acc = [e_1 | ... | e_k] [w_1 W_1 | ... | w_k W_k]^T + sum_k w_k b_k, fp32 out of the GEMM
+    (bf16 operands, fp32 accumulation across ALL scales: one rounding less per scale than k separate GEMM outputs).  Costs a
+    transient [N, sum dims] operand, so MultiScaleFusion uses it while that is small (every benchmarked single-GPU workload
+    except the 10M-node graph) and the streaming form above otherwise.  Backward: one data-gradient GEMM, one weight-gradient
+    GEMM in fp32, the scalar weights' gradients from column sums of dW * W."""
+
+    @staticmethod
+    def forward(ctx, weights, cd, seg, onehot, *args):
+        k = len(args) // 3
+        embs, ws, bs = args[:k], args[k:2 * k], args[2 * k:]
+        with torch.autocast("cuda", enabled=False):
+            x = torch.cat([e if e.dtype == cd else e.to(cd) for e in embs], 1)            # [N, D]
+            wcat = torch.cat([w.float() for w in ws], 1)                                    # [P, D] fp32, unscaled
+            srow = weights.float().index_select(0, seg)                                     # [D]: w_k of each column's scale
+            wc = (wcat * srow).to(cd)
+            acc = _mm_f32(x, wc)
+            bstack = torch.stack([b.float() for b in bs])                                   # [k, P]
+            acc.add_(weights.float() @ bstack)
+        ctx.save_for_backward(weights, x, wcat, wc, srow, bstack, onehot)
+        ctx.cd, ctx.k, ctx.dims, ctx.emb_dtypes = cd, k, [e.shape[1] for e in embs], [e.dtype for e in embs]
+        return acc
+
+    @staticmethod
+    def backward(ctx, g):
+        weights, x, wcat, wc, srow, bstack, onehot = ctx.saved_tensors
+        k, cd, dims = ctx.k, ctx.cd, ctx.dims
+        with torch.autocast("cuda", enabled=False):
+            g_cd = g.to(cd)
+            gsum = ops.column_sum(g)                                                        # [P] fp32
+            dx = g_cd @ wc                                                                  # [N, D]
+            d_embs = [t if t.dtype == dt else t.to(dt) for t, dt in zip(dx.split(dims, 1), ctx.emb_dtypes)]
+            dwc = _splitk_wgrad(g_cd, x, keep_fp32=True)                                    # [P, D] fp32: gradient of the SCALED weights
+            d_ws = list((dwc * srow).split(dims, 1))
+            colsum = ops.column_sum(dwc * wcat)                                             # [D]: sum_p dW[p, c] W[p, c]
+            d_weights = (onehot @ colsum + bstack @ gsum).to(weights.dtype)
+            d_bs = list((weights.float().view(-1, 1) * gsum.view(1, -1)).unbind(0))
+        return (d_weights, None, None, None, *d_embs, *d_ws, *d_bs)
+
+
+def _mm_f32(a, b):
+    """a [N, K] @ b [P, K]^T with an fp32 result straight out of the GEMM when the operands are 16-bit."""
+    if a.dtype != torch.float32 and _F32_MM[0]:
+        try:
+            return torch.mm(a, b.t(), out_dtype=torch.float32)
+        except (RuntimeError, TypeError):
+            _F32_MM[0] = False
+    return (a @ b.t()).float()
+
+
 class MultiScaleFusion(nn.Module):
     """main.py:167-180: LayerNorm(sum_k softmax(w)_k * Linear_k(emb_k))."""
 
@@ -544,11 +594,29 @@ class MultiScaleFusion(nn.Module):
         self.projections = nn.ModuleList([nn.Linear(dim, output_dim) for dim in hidden_dims])
         self.layer_norm = nn.LayerNorm(output_dim)
         self.compute_dtype: Optional[torch.dtype] = None
+        self.cat_bytes_limit = 1 << 30          # largest transient [N, sum dims] operand of the one-GEMM form (_ScaledProjectionCat)
+        self._seg = None
+
+    def _segments(self, dims, device):
+        """(int64 [sum dims]: index of the scale every concatenated column belongs to, fp32 [k, sum dims]: the same as a one-hot
+        matrix), built once per device / geometry."""
+        if self._seg is None or self._seg[0] != (tuple(dims), device):
+            seg = torch.repeat_interleave(torch.arange(len(dims)), torch.tensor(dims)).to(device)
+            onehot = torch.zeros(len(dims), seg.numel(), device=device).scatter_(0, seg.view(1, -1), 1.0)
+            self._seg = ((tuple(dims), device), seg, onehot)
+        return self._seg[1], self._seg[2]
 
     def forward(self, embeddings_list):
         cd = compute_dtype(self.compute_dtype)
         weights = F.softmax(self.scale_weights.float(), dim=0)
-        acc = _ScaledProjectionSum.apply(weights, cd, *embeddings_list, *[p.weight for p in self.projections],
-                                         *[p.bias for p in self.projections])
+        dims = [e.shape[1] for e in embeddings_list]
+        n_rows = embeddings_list[0].shape[0]
+        if embeddings_list[0].is_cuda and n_rows * sum(dims) * 2 <= self.cat_bytes_limit:
+            seg, onehot = self._segments(dims, embeddings_list[0].device)
+            acc = _ScaledProjectionCat.apply(weights, cd, seg, onehot, *embeddings_list, *[p.weight for p in self.projections],
+                                             *[p.bias for p in self.projections])
+        else:
+            acc = _ScaledProjectionSum.apply(weights, cd, *embeddings_list, *[p.weight for p in self.projections],
+                                             *[p.bias for p in self.projections])
         ln = self.layer_norm
         return ops.bias_res_layernorm(acc, None, None, ln.weight, ln.bias, ln.eps)

@@ -147,16 +147,17 @@ def lin_noround(x, w):
 
 
 class _ScaledProjectionSum(torch.autograd.Function):
-    """MultiScaleFusion ahead of its LayerNorm (main.py:176-179): acc = sum_k bf16(e_k~ bf16(w_k s_k)^T) + sum_k b_k s_k, fp32
-    accumulator; backward with the gradient rounded once to bf16 for the GEMMs."""
+    """MultiScaleFusion ahead of its LayerNorm (main.py:176-179): acc = sum_k e_k~ bf16(w_k s_k)^T + sum_k b_k s_k as ONE GEMM
+    over the concatenated operands (fp32 accumulation and fp32 output: nn._ScaledProjectionCat); backward with the gradient
+    rounded once to bf16 for the GEMMs, weight gradients fp32."""
 
     @staticmethod
     def forward(ctx, weights, *args):
         k = len(args) // 3
         embs, ws, bs = args[:k], args[k:2 * k], args[2 * k:]
         acc = None
-        for i in range(k):
-            t = r(embs[i] @ r(ws[i] * weights[i]).t())
+        for i in range(k):                                   # ONE GEMM over the concatenated operands: fp32 out, no rounding per scale
+            t = embs[i] @ r(ws[i] * weights[i]).t()
             acc = t if acc is None else acc + t
         acc = acc + sum(bs[i] * weights[i] for i in range(k))
         ctx.save_for_backward(weights, *embs, *ws, *bs)
@@ -173,7 +174,7 @@ class _ScaledProjectionSum(torch.autograd.Function):
         d_embs, d_ws, d_bs = [], [], []
         for i in range(k):
             d_embs.append(r(gc @ r(ws[i] * weights[i])))
-            dws = r(gc.t() @ embs[i])
+            dws = gc.t() @ embs[i]                            # fp32 weight-gradient GEMM output
             d_ws.append(dws * weights[i])
             d_bs.append(gsum * weights[i])
             d_weights[i] = (dws * ws[i]).sum() + (gsum * bs[i]).sum()

@@ -400,3 +400,44 @@ def test_edge_case_graphs_vs_oracle(dev, case):
             assert p is None or float(p.abs().max()) == 0
             continue
         np.testing.assert_allclose(p.cpu().numpy(), r.numpy(), rtol=2e-3, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_multi_scale_fusion_one_gemm_form_equals_streaming_form(dev, cd):
+    """MultiScaleFusion (main.py:167-180): the one-GEMM form over the concatenated scales (nn._ScaledProjectionCat) against the
+    streaming form (nn._ScaledProjectionSum, what the 10M-node graph uses) and, in fp32, against the module's plain definition."""
+    import gmlm_amd
+    g = torch.Generator().manual_seed(5)
+    dims, p, n = [32, 64, 128, 256], 96, 777
+    ref = torch.nn.ModuleList([torch.nn.Linear(d, p) for d in dims]).to(dev)
+    embs = [torch.randn(n, d, generator=g).to(dev, cd) for d in dims]
+    go = torch.randn(n, p, generator=g).to(dev)
+
+    def run(limit):
+        m = gmlm_amd.MultiScaleFusion(dims, p).to(dev)
+        m.compute_dtype = cd
+        m.cat_bytes_limit = limit
+        with torch.no_grad():
+            m.scale_weights.copy_(torch.tensor([0.1, 0.4, -0.3, 0.2]))
+            for a, b in zip(m.projections, ref):
+                a.weight.copy_(b.weight); a.bias.copy_(b.bias)
+        xs = [e.clone().requires_grad_(True) for e in embs]
+        y = m(xs)
+        y.backward(go)
+        return y.detach(), [x.grad for x in xs], {k: v.grad for k, v in m.named_parameters()}
+
+    y1, dx1, dp1 = run(1 << 30)
+    y0, dx0, dp0 = run(0)
+    tol = 2e-5 if cd == torch.float32 else 2e-2
+    assert float((y1 - y0).abs().max()) <= tol * float(y0.abs().max())
+    for a, b in zip(dx1, dx0):
+        assert float((a.float() - b.float()).abs().max()) <= tol * float(b.float().abs().max())
+    for k in dp0:
+        assert float((dp1[k] - dp0[k]).abs().max()) <= tol * float(dp0[k].abs().max()) + 1e-7, k
+    if cd == torch.float32:
+        w = torch.softmax(torch.tensor([0.1, 0.4, -0.3, 0.2], device=dev), 0)
+        plain = sum(w[i] * ref[i](embs[i]) for i in range(4))
+        m = gmlm_amd.MultiScaleFusion(dims, p).to(dev)
+        plain = torch.nn.functional.layer_norm(plain, (p,), m.layer_norm.weight, m.layer_norm.bias, m.layer_norm.eps)
+        assert float((y1 - plain).abs().max()) <= 2e-5 * float(plain.abs().max())
