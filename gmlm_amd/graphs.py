@@ -131,6 +131,8 @@ class GraphedStep:
             edge_index, edge_type = self._graph_args
 
             def step_fn(x, *t):
+                from . import nn as _nn
+                _nn.DCOMP_BY_GEMM = True             # (the backward is recorded right after this forward: see reset below)
                 model._branch_stream = self._side2
                 cur = torch.cuda.current_stream()
                 side.wait_stream(cur)                                        # fork (behind the seed bump of _Region.forward)
@@ -154,7 +156,11 @@ class GraphedStep:
             samples = (xs,) + tuple(t.clone() for t in tables)
             used = _touched_params(model, lambda: step_fn(*samples).sum().backward())
             xs.grad = None
-            region = torch.cuda.make_graphed_callables(_Region(step_fn, used, self.counter, True), samples, num_warmup_iters=2)
+            from . import nn as _nn
+            try:
+                region = torch.cuda.make_graphed_callables(_Region(step_fn, used, self.counter, True), samples, num_warmup_iters=2)
+            finally:
+                _nn.DCOMP_BY_GEMM = False
             while len(self._steps) >= self.encoder_buckets:
                 self._steps.pop(next(iter(self._steps)))
             hit = (tokens, region)
@@ -176,7 +182,9 @@ def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type:
     encoder and GNN branches run side by side (``GraphedStep.step``; a step whose text batch needs several micro-batches falls
     back to the separate regions).  Opt-in because of an open issue: with branches, about one step in thirty returned ONE small
     gradient tensor (``rgcn4.comp``, 5 x 30) off by up to 1 % - the basis-composition backward kernel wrote wrong per-block
-    partial sums from inputs that were right; the three linear recordings replay bit for bit.  ``model.release_hip_graphs()`` drops the recordings."""
+    partial sums from inputs that were right.  Inside such a recording that product is now formed by a
+    GEMM (``nn.DCOMP_BY_GEMM``), which never showed the effect, but the cause is not understood; the three linear recordings
+    replay bit for bit and stay the default.  ``model.release_hip_graphs()`` drops the recordings."""
     model._graphed = None
     g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder, whole_step)
     model._graphed = g

@@ -332,7 +332,15 @@ class _BasisCompose(torch.autograd.Function):
         ops.check(ops.lib().gmlm_basis_compose_bwd(ops._ptr(comp_a), ops._ptr(weight2d), ops._ptr(dw), ra, nb, cols,
                                                    ops._ptr(dweight), ops._ptr(dcomp), ops._ptr(ws), ws.numel(), ops._stream()),
                   "gmlm_basis_compose_bwd")
+        if DCOMP_BY_GEMM:
+            # see graphs.GraphedStep.step: inside a recording with parallel branches this kernel's dcomp accumulators (108 long-
+            # lived registers per lane) sporadically came out wrong while dweight, from the same loads, was right; the
+            # same product as a GEMM over the tensors in memory never did (24 runs x 8 replays, graph against graph)
+            dcomp = dw @ weight2d.t()
         return dcomp, dweight, None
+
+
+DCOMP_BY_GEMM = False        # set while a branched whole-step hipGraph is recorded (graphs.py)
 
 
 class RGCNConv(nn.Module):

@@ -92,17 +92,15 @@ def _step(m, x, ei, y, tokens, mask, plm_batch=64):
 
 
 def _same_gradients(g0, g1, branched):
-    """Linear recordings: every gradient bit for bit.  The opt-in whole-step graph with parallel branches has an OPEN ISSUE
-    (DESIGN.md section 5): about one replay in thirty returns the gradient of one ``rgcn*.comp`` (5 x 30) off by up to 1 % - the
-    basis-composition backward wrote wrong per-block partial sums from inputs that were right; eager-vs-eager never differs.
-    Its test therefore allows that, and only that: at most one ``.comp`` tensor per step, within 3 % of its largest entry."""
-    off = [k for k in g0 if not torch.equal(g0[k], g1[k])]
-    if not branched:
-        assert not off, off
-        return
-    assert len(off) <= 1 and all(k.endswith(".comp") for k in off), off
-    for k in off:
-        assert float((g0[k] - g1[k]).abs().max()) <= 3e-2 * float(g0[k].abs().max()), k
+    """Linear recordings: every gradient bit for bit.  The opt-in whole-step graph with parallel branches forms the gradient of
+    the basis coefficients (``rgcn*.comp``) with a GEMM instead of the kernel's in-register sums (nn.DCOMP_BY_GEMM, DESIGN.md
+    section 5: inside a branched recording the kernel's sums sporadically came out wrong): those four 5 x 30 tensors agree to
+    fp32 summation order, everything else bit for bit."""
+    for k in g0:
+        if branched and k.endswith(".comp"):
+            assert float((g0[k] - g1[k]).abs().max()) <= 2e-5 * float(g0[k].abs().max()) + 1e-9, k
+        else:
+            assert torch.equal(g0[k], g1[k]), k
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])

@@ -12,6 +12,8 @@ import test_gpu_graphs as T
 from test_gpu_model import build_model
 
 dev = torch.device("cuda:0")
+import gmlm_amd.nn as _nn
+_nn.DCOMP_BY_GEMM = bool(os.environ.get("DCOMP_GEMM"))   # (graphs.GraphedStep.step sets it for its own recording anyway)
 cd = torch.bfloat16 if os.environ.get("BF16") else torch.float32
 mode = sys.argv[1] if len(sys.argv) > 1 else "enc"
 cfg = T._cfg(0.0)
