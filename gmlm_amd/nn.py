@@ -336,11 +336,24 @@ class _BasisCompose(torch.autograd.Function):
             # see graphs.GraphedStep.step: inside a recording with parallel branches this kernel's dcomp accumulators (108 long-
             # lived registers per lane) sporadically came out wrong while dweight, from the same loads, was right; the
             # same product as a GEMM over the tensors in memory never did (24 runs x 8 replays, graph against graph)
-            dcomp = dw @ weight2d.t()
+            dcomp = _rowdot_batched(dw, weight2d)
         return dcomp, dweight, None
 
 
 DCOMP_BY_GEMM = False        # set while a branched whole-step hipGraph is recorded (graphs.py)
+
+
+def _rowdot_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a [R, K] @ b [B, K]^T for tiny R, B and a very long K (K = in * out of an RGCN layer): ONE GEMM with M = 3, N = 30,
+    K = 2 * 10^6 runs on a handful of workgroups; cut K into up to 256 slices, batch them, add the slices (fp32)."""
+    k = a.shape[1]
+    s = 256
+    while s > 1 and (k % s or k // s < 512):
+        s //= 2
+    if s == 1:
+        return a @ b.t()
+    prod = torch.bmm(a.view(a.shape[0], s, k // s).transpose(0, 1), b.view(b.shape[0], s, k // s).permute(1, 2, 0))   # [s, R, B]
+    return prod.sum(0)
 
 
 class RGCNConv(nn.Module):
@@ -392,7 +405,7 @@ class RGCNConv(nn.Module):
         with torch.autocast("cuda", enabled=False):
             w = self.relation_weights(csr, x.dtype, in_pad, reducer)
             if bc is not None and rootc.shape[0] == x.shape[1]:
-                out = _RootAddmm.apply(x[:n], rootc, bc, self.root, self.bias)       # shadow operands, fp32 gradients to the masters
+                out = _RootAddmm.apply(x if x.shape[0] == n else x[:n], rootc, bc, self.root, self.bias)   # shadow operands, fp32 gradients to the masters
             else:
                 root = self.root if not in_pad else F.pad(self.root, (0, 0, 0, in_pad))
                 out = torch.addmm(self.bias.to(x.dtype), x[:n], root.to(x.dtype))
@@ -477,8 +490,23 @@ class CrossAttention(nn.Module):
             return _linear(o, self.out_proj.weight, self.out_proj.bias)
         if kv_gather is not None:
             kv = kv_gather(kv)
-        o = attention_any_dim(q, kv[..., :c], kv[..., c:], None, self.num_heads, self.scale, self.dropout.p, self.training)
+        k, v = _SplitLast.apply(kv, c)
+        o = attention_any_dim(q, k, v, None, self.num_heads, self.scale, self.dropout.p, self.training)
         return _linear(o, self.out_proj.weight, self.out_proj.bias)
+
+
+class _SplitLast(torch.autograd.Function):
+    """(x[..., :c], x[..., c:]) as views; the backward is ONE concatenation of the two gradients instead of autograd's two
+    zero-filled full-size buffers, two slice copies and an add."""
+
+    @staticmethod
+    def forward(ctx, x, c):
+        ctx.c = c
+        return x[..., :c], x[..., c:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        return torch.cat([ga, gb], -1), None
 
 
 def attention_any_dim(q, k, v, kv_len, num_heads, scale, dropout_p, training):

@@ -763,3 +763,18 @@ def test_device_split_plan_matches_host_plan(dev, case):
     assert torch.equal(a, b)
     assert float((a.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
     assert float((c.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,f", [(1, 5), (7, 33), (2277, 256), (8192, 768), (8193, 96), (40960, 256)])
+def test_column_sum_paths(dev, dtype, n, f):
+    """ops.column_sum (bias gradients): the fixed-order two-pass column reduction against fp64; bit-deterministic.  (A one-launch
+    kernel for short matrices - 32 columns x 8 row lanes per block - was measured and removed: 8 blocks walking 2,277 rows
+    take longer than the two launches they replace.)"""
+    from gmlm_amd import ops
+    g = torch.Generator().manual_seed(n * 131 + f)
+    x = torch.randn(n, f, generator=g).to(dev, dtype)
+    a, b = ops.column_sum(x), ops.column_sum(x)
+    ref = x.double().sum(0)
+    assert a.dtype == torch.float32 and torch.equal(a, b)
+    assert float((a.double() - ref).abs().max()) <= 2e-6 * float(x.double().abs().sum(0).max()) + 1e-9
