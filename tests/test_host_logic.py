@@ -112,3 +112,29 @@ def test_bucketed_layout_invariants():
         la2, s2, t2, g2 = bucketed_layout(lens[:-1] if lens else lens, cap, True, quanta)
         assert (s2, t2) == (s_b, t_b) or n_real == 0 or abs(s2 - s_b) == sq or abs(t2 - t_b) == tq
     assert bucketed_layout([5, 7], 12, False)[3] is None
+
+
+def test_param_shadow_layout_and_small_autograd_helpers():
+    """nn.ParamShadow (compute-dtype operands of a region in one flat buffer), nn._SplitLast (K|V split whose backward is one
+    concatenation), nn._rowdot_batched (basis-coefficient gradient as a K-sliced batched GEMM): host-checkable pieces of the
+    kernel-count work - same values as the plain torch expressions they replace."""
+    from gmlm_amd import nn as gnn
+    g = torch.Generator().manual_seed(3)
+    w1, w2 = torch.randn(5, 7, generator=g), torch.randn(3, 7, generator=g)
+    b1, root = torch.randn(5, generator=g), torch.randn(6, 4, generator=g)
+    sh = gnn.ParamShadow([("kv", [w1, w2], 0), (id(b1), [b1], 0), (id(root), [root], 2)], torch.bfloat16, torch.device("cpu"))
+    assert torch.equal(sh.get("kv"), torch.cat([w1, w2], 0).to(torch.bfloat16))
+    assert torch.equal(sh.get(id(b1)), b1.to(torch.bfloat16))
+    r = sh.get(id(root))
+    assert r.shape == (8, 4) and torch.equal(r[:6], root.to(torch.bfloat16)) and float(r[6:].abs().max()) == 0.0   # pad rows stay zero
+    assert sh.get("missing") is None
+    for v in sh.views.values():
+        assert v.is_contiguous() and v.data_ptr() % 256 == sh.get("kv").data_ptr() % 256                          # 256-byte aligned slots
+    x = torch.randn(4, 10, generator=g, requires_grad=True)
+    a, b = gnn._SplitLast.apply(x, 6)
+    (a.sum() * 2 + (b * b).sum()).backward()
+    ref = torch.cat([torch.full((4, 6), 2.0), 2 * x.detach()[:, 6:]], 1)
+    assert torch.equal(x.grad, ref)
+    p, q = torch.randn(3, 4096 * 3, generator=g), torch.randn(30, 4096 * 3, generator=g)
+    assert torch.allclose(gnn._rowdot_batched(p, q), p @ q.t(), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(gnn._rowdot_batched(p[:, :100], q[:, :100]), p[:, :100] @ q[:, :100].t(), rtol=1e-5, atol=1e-4)   # too short to slice
