@@ -182,6 +182,20 @@ def _oracle_vs_hip(dev, name, hc, plm, cd, atol, max_len=24, bs=32):
             a, b = p.grad.detach().double().cpu().reshape(-1), r.double().reshape(-1)
             cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
             assert cos >= 0.97, (k, cos)
+    if cd == torch.bfloat16:
+        # the budget above is what 8-bit mantissas cost against fp32; the CHECK of the bf16 path is the oracle's bf16-emulating
+        # mode (oracle/bf16_emulation.py: fp32 arithmetic, rounded where the kernels round): logits (bf16 numbers: grid 2^-8 ..
+        # 2^-7 around 1) within two ulps and far closer on average than either side is to fp32, loss to 1e-3
+        import bf16_emulation as E
+        with torch.no_grad():
+            le = E.forward(om, data["x"], data["edge_index"], ids, am, mask)
+        de = (logits.detach().float().cpu() - le).abs()
+        d32 = (logits.detach().float().cpu() - ref.detach()).abs()
+        loss_e = F.cross_entropy(le[mask], data["y"][mask], label_smoothing=0.2)
+        print(f"\n{name} bf16 HIP vs emulation: logits max {float(de.max()):.3e} mean {float(de.mean()):.3e} (vs fp32 oracle: max "
+              f"{float(d32.max()):.3e} mean {float(d32.mean()):.3e}); dloss {abs(float(loss) - float(loss_e)):.2e}")
+        assert float(de.max()) <= 1.6e-2 and float(de.mean()) <= 2.5e-3 and abs(float(loss) - float(loss_e)) <= 1e-3
+        assert float(de.mean()) < 0.7 * float(d32.mean())
     return float(loss), float(loss_ref)
 
 
@@ -196,7 +210,7 @@ def test_chameleon_size_bf16_vs_oracle(dev):
     """Same config with bf16 GEMM/attention operands (fp32 accumulation and statistics).  bf16 has an
     8-bit mantissa: logits O(1) agree to ~3e-2 after 4 GNN + 4 BERT layers; this is the bench dtype."""
     plm = dict(hidden=256, layers=4, heads=4, inter=1024, max_pos=64, vocab=200)
-    l, lr = _oracle_vs_hip(dev, "chameleon", 256, plm, torch.bfloat16, 6e-2)
+    l, lr = _oracle_vs_hip(dev, "chameleon", 256, plm, torch.bfloat16, 3e-2)            # measured 1.3e-2 against fp32; the check proper is the emulation inside
     assert abs(l - lr) < 3e-2
 
 
