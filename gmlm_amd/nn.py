@@ -81,7 +81,7 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor, keep_fp32: bool = False) 
     k = x2.shape[1]
     tiles = ((n + 255) // 256) * ((k + 255) // 256)
     s = 1
-    if tiles < 128 and t >= 4096:
+    if tiles < 128 and t >= 16384:                    # (node-level layers, t = a few thousand rows: one GEMM; slicing them left a tail GEMM + an add per weight)
         import math
         # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
         s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))

@@ -1,18 +1,20 @@
-"""Which autograd nodes / python frames launch the small torch kernels of a Chameleon-size step (eager mode).
-usage: python tools/dev/op_trace.py [aten op substring, default fill_]"""
+"""Which autograd nodes / aten parents launch a given torch op in one eager step.
+usage: python tools/dev/op_trace.py [aten op substring, default fill_] [workload, default chameleon]"""
 import sys, os, collections
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch, torch.nn.functional as F
 import bench
 want = sys.argv[1] if len(sys.argv) > 1 else "fill_"
+wl = sys.argv[2] if len(sys.argv) > 2 else "chameleon"
+geo = {"chameleon": (256, 256, 4), "cornell": (512, 768, 12)}.get(wl, (768, 768, 12))
 sys.argv = ["bench.py", "--workload", "chameleon"]
 import argparse
 # reuse bench's builders
-ap_defaults = dict(workload="chameleon", hc=256, plm_hidden=256, plm_layers=4, vocab=30522, max_len=128, dtype="bf16", plm_batch=4096,
+ap_defaults = dict(workload=wl, hc=geo[0], plm_hidden=geo[1], plm_layers=geo[2], vocab=30522, max_len=128, dtype="bf16", plm_batch=4096,
                    reference_recompute=False, overlap_streams=False, plm_ckpt=False, activation_ckpt=False, act_ckpt=False)
 args = argparse.Namespace(**ap_defaults)
 dev = torch.device("cuda:0")
-data = bench.synthetic("chameleon", n_parts=1)
+data = bench.synthetic(wl, n_parts=1)
 ids, am = bench.synthetic_tokens(data["n"], 128, 30522, seed=data["n"])
 model = bench.build_model(args, data, dev)
 import gmlm_amd
