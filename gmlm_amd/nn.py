@@ -557,7 +557,7 @@ class _ScaledProjectionSum(torch.autograd.Function):
         weights = ctx.saved_tensors[0]
         embs, ws, bs = ctx.saved_tensors[1:1 + k], ctx.saved_tensors[1 + k:1 + 2 * k], ctx.saved_tensors[1 + 2 * k:]
         g_cd = g.to(cd)
-        gsum = g.sum(0)
+        gsum = ops.column_sum(g) if g.is_cuda else g.sum(0)
         d_weights = torch.zeros_like(weights)
         d_embs, d_ws, d_bs = [], [], []
         with torch.autocast("cuda", enabled=False):

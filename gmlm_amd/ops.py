@@ -699,7 +699,7 @@ class EmbedSum(torch.autograd.Function):
             _spmm(g32, rowptr, perm, None, False, nseg, p, acc, device_split_plan(rowptr, ids.numel()))
             grads.append(acc)
         d_type = torch.zeros(ntype, p, dtype=torch.float32, device=g.device)
-        d_type[0] = grads[1].sum(0)
+        d_type[0] = column_sum(grads[1])                   # (not ATen's global reduction: see column_sum)
         return None, None, grads[0], grads[1], d_type, None, None
 
 
