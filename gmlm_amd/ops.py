@@ -171,9 +171,9 @@ def _spmm(src, rowptr, idx, edge_w, mean, num_segments, f, out, split=None):
 
 def column_sum(x: torch.Tensor) -> torch.Tensor:
     """fp32 column sums of a 2-D fp32 / bf16 tensor on the K4 statistics kernel (fixed-order partials, deterministic): the bias
-    gradients of the dense layers.  (``x.sum(0, dtype=float32)`` - ATen's reduction with its semaphore buffer - gave wrong sums
-    from the fourth replay on inside one recorded hipGraph, tests/test_gpu_graphs.py; this kernel needs no zero-initialised
-    scratch.)"""
+    gradients of the dense layers.  (``x.sum(0, dtype=float32)`` - ATen's reduction, on shapes that take its cross-block path
+    with a semaphore buffer - goes wrong from the second replay on inside a recorded hipGraph on this PyTorch / ROCm stack:
+    tools/dev/aten_sum_graph_repro.py; this kernel needs no zero-initialised scratch.)"""
     _cuda(x)
     x = x.contiguous()
     n, f = x.shape
