@@ -91,7 +91,7 @@ int col_reduce(int64_t n, int64_t f, Fn fn, float* out, void* workspace, size_t 
                float scale = 1.f) {
   if (f <= 0) return GMLM_OK;
   if (n <= 0) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * K * f, st);
+    hipError_t e = zero_async(out, sizeof(float) * K * f, st);
     if (e != hipSuccess) { set_error("memset failed: %s", hipGetErrorString(e)); return GMLM_ELAUNCH; }
     return GMLM_OK;
   }

@@ -124,6 +124,20 @@ template <> struct Store<bf16_t> {
   }
 };
 
+// ---- zero fill as a KERNEL ---------------------------------------------------------------------
+// Not hipMemsetAsync: a memset node recorded into a hipGraph writes a wrong value from the second replay on with this ROCm /
+// PyTorch stack (tools/dev/memset_graph_probe.py), and every entry of this library may be called under stream capture.
+static __global__ void zero_words_kernel(uint32_t* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t zero_async(void* p, size_t bytes, hipStream_t st) {      // bytes: a multiple of 4
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  const size_t blocks = (n + 255) / 256;
+  zero_words_kernel<<<(unsigned)(blocks > 4096 ? 4096 : blocks), 256, 0, st>>>(static_cast<uint32_t*>(p), n);
+  return hipGetLastError();
+}
+
 // ---- wave64 reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

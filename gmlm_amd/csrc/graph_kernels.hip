@@ -101,7 +101,7 @@ extern "C" int gmlm_degree_i32(const int64_t* index, int64_t e, int64_t n, int32
   GMLM_REQUIRE(n >= 0 && e >= 0 && (n == 0 || deg) && (e == 0 || index), "degree: bad arguments (n=%ld e=%ld)", (long)n, (long)e);
   GMLM_REQUIRE(n < (1ll << 31), "degree: n=%ld exceeds int32 range", (long)n);
   if (n == 0) return GMLM_OK;
-  GMLM_HIP(hipMemsetAsync(deg, 0, sizeof(int32_t) * n, as_stream(stream)));
+  GMLM_HIP(zero_async(deg, sizeof(int32_t) * n, as_stream(stream)));
   if (e == 0) return GMLM_OK;
   degree_kernel<<<grid_cap(cdiv(e, 256)), 256, 0, as_stream(stream)>>>(index, e, n, deg);
   GMLM_LAUNCH_CHECK();
@@ -131,7 +131,7 @@ extern "C" int gmlm_relation_histogram(const int64_t* edge_type, int64_t e, int 
                                        gmlm_stream_t stream) {
   GMLM_REQUIRE(num_relations > 0 && num_relations <= 64 && rel_count && (e == 0 || edge_type),
                "relation_histogram: num_relations must be in [1, 64]");
-  GMLM_HIP(hipMemsetAsync(rel_count, 0, sizeof(int32_t) * num_relations, as_stream(stream)));
+  GMLM_HIP(zero_async(rel_count, sizeof(int32_t) * num_relations, as_stream(stream)));
   if (e == 0) return GMLM_OK;
   rel_hist_kernel<<<grid_cap(cdiv(e, 256), 1024), 256, 0, as_stream(stream)>>>(edge_type, e, num_relations, rel_count);
   GMLM_LAUNCH_CHECK();
@@ -153,9 +153,9 @@ extern "C" int gmlm_segment_sort(const int64_t* node, const int64_t* rel, const 
   GMLM_REQUIRE(num_segments < (1ll << 31) - 1 && e < (1ll << 31) - 1, "segment_sort: int32 index range exceeded");
   GMLM_REQUIRE(workspace_bytes >= gmlm_segment_sort_workspace_bytes(e), "segment_sort: workspace too small");
   hipStream_t st = as_stream(stream);
-  GMLM_HIP(hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st));
+  GMLM_HIP(zero_async(bad_flag, sizeof(int32_t), st));
   if (e == 0) {
-    GMLM_HIP(hipMemsetAsync(rowptr, 0, sizeof(int32_t) * (num_segments + 1), st));
+    GMLM_HIP(zero_async(rowptr, sizeof(int32_t) * (num_segments + 1), st));
     return GMLM_OK;
   }
   char* ws = static_cast<char*>(workspace);

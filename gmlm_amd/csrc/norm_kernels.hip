@@ -552,9 +552,9 @@ extern "C" int gmlm_bias_res_layernorm_bwd(const void* dy, const void* x, const 
   if (rc != GMLM_OK) return rc;
   hipStream_t st = as_stream(stream);
   if (rows == 0) {
-    if (dgamma) GMLM_HIP(hipMemsetAsync(dgamma, 0, sizeof(float) * f, st));
-    if (dbeta) GMLM_HIP(hipMemsetAsync(dbeta, 0, sizeof(float) * f, st));
-    if (dbias) GMLM_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * f, st));
+    if (dgamma) GMLM_HIP(zero_async(dgamma, sizeof(float) * f, st));
+    if (dbeta) GMLM_HIP(zero_async(dbeta, sizeof(float) * f, st));
+    if (dbias) GMLM_HIP(zero_async(dbias, sizeof(float) * f, st));
     return GMLM_OK;
   }
   GMLM_REQUIRE(dy && x && gamma && beta && mean && rstd && dx, "bias_res_layernorm_bwd: null pointer");

@@ -274,7 +274,7 @@ extern "C" int gmlm_bias_gelu_bwd(const void* dy, const void* x, const float* bi
   if (rc != GMLM_OK) return rc;
   hipStream_t st = as_stream(stream);
   if (rows == 0) {
-    if (dbias) GMLM_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * f, st));
+    if (dbias) GMLM_HIP(zero_async(dbias, sizeof(float) * f, st));
     return GMLM_OK;
   }
   GMLM_REQUIRE(dy && x && dx && aligned16(dy) && aligned16(x) && aligned16(dx), "bias_gelu_bwd: null or misaligned pointer");
