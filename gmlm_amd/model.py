@@ -502,7 +502,9 @@ class GraphTextLM(nn.Module):
         fn, c = self.fusion_network, self.classifier
         specs = (cross_attention_specs(self.graph_to_text_attn) + cross_attention_specs(self.text_to_graph_attn)
                  + linear_specs(c[3]) + [(id(fn[0].weight), [fn[0].weight], 0), (id(c[0].weight), [c[0].weight], 0)])
-        with shadow_params(specs, cd, gnn_embeds.device):
+        with shadow_params(specs, cd, gnn_embeds.device) as sh:
+            if sh is not None and self._branch_stream is not None and self.dist is None:
+                sh.record_stream(self._branch_stream)              # the second cross-attention reads its operands on the branch
             return self._head_body(gnn_embeds, plm_embeds, cd)
 
     def _head_body(self, gnn_embeds, plm_embeds, cd):

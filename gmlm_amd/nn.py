@@ -186,6 +186,7 @@ class ParamShadow:
         self.dtype = dtype
         with torch.no_grad():
             flat = torch.zeros(total, dtype=dtype, device=device)
+            self.flat = flat
             self.views, dsts, srcs = {}, [], []
             for key, masters, shape, off, numel in plan:
                 v = flat[off:off + numel].view(shape)
@@ -200,6 +201,12 @@ class ParamShadow:
 
     def get(self, key):
         return self.views.get(key)
+
+    def record_stream(self, stream) -> None:
+        """The operands are also read by kernels on ``stream`` (a branch of a recorded step): keep the allocator from recycling
+        the buffer on its own stream while that branch still runs."""
+        if self.flat.is_cuda:
+            self.flat.record_stream(stream)
 
 
 _SHADOW: Optional[ParamShadow] = None
