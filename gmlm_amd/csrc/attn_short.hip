@@ -30,6 +30,9 @@ namespace gmlm {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
+#ifndef GMLM_SHORT_FWD_OCC
+#define GMLM_SHORT_FWD_OCC 4
+#endif
 constexpr int kShortMaxSeq = 13;   // sequences per group: ids 0..12; 14 = padding query row, 15 = padding key row
 
 // A fragment of the mask step for a tile row with sequence id `id`: 1 in column id (elements j = 0..7 <-> columns 8h + j)
@@ -117,7 +120,7 @@ __device__ __forceinline__ void block_range(const int16_t* lo, const int16_t* hi
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int D, bool DROP, int R>
-__global__ __launch_bounds__(2 * R) void attn_fwd_short_kernel(AttnParams p) {
+__global__ __launch_bounds__(2 * R, GMLM_SHORT_FWD_OCC) void attn_fwd_short_kernel(AttnParams p) {
   using T = bf16_t;
   static_assert(D == 64, "dense swizzled images are laid out for d = 64");
   constexpr int NT = 2 * R, PITCH = D, DB = D / 32, CPR = D / 8, PER = R * CPR / NT, NB = R / 32;
