@@ -528,6 +528,7 @@ def main():
     ap.add_argument("--cpu-hc", type=int, default=768)
     ap.add_argument("--no-encoder-graph", action="store_true", help="with hipGraphs: leave the text encoder eager (GNN + head regions only)")
     ap.add_argument("--overlap-streams", action="store_true", help="text encoder on a second HIP stream beside the GNN (model.overlap_streams)")
+    ap.add_argument("--concurrent-graphs", action="store_true", help="with hipGraphs: replay the (linear) GNN and encoder recordings on two streams at once")
     ap.add_argument("--whole-step-graph", action="store_true", help="with hipGraphs: ONE graph per step with the encoder and GNN branches side by side instead of three linear recordings (faster; opt-in, see graphs.capture)")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile the timed steps (host side) and write the top entries to FILE")
     ap.add_argument("--no-kernel-timers", action="store_true")
@@ -613,7 +614,7 @@ def main():
         if distributed:
             raise SystemExit("--hip-graph is single-GPU")
         model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei, encoder=not args.no_encoder_graph,
-                                 whole_step=args.whole_step_graph)
+                                 whole_step=args.whole_step_graph, concurrent=args.concurrent_graphs)
 
     def step():
         model.zero_grad(set_to_none=True)
@@ -680,7 +681,8 @@ def main():
                    "recompute_note": "the reference recomputes RGCN blocks and BertLayers in backward (main.py:217-219, 278-314); this line runs "
                                      + ("WITH both, like the reference" if all(recompute_flags(args)) else "WITHOUT recomputation (same results; the reference-mode time is in reference_recompute)"),
                    "world": world, "backend": (torch.distributed.get_backend() if distributed else None), "devices": devices,
-                   "hip_graph": ("whole-step graph with parallel branches" if args.whole_step_graph else "three linear recordings (GNN, text encoder per size bucket, head)") if args.hip_graph else False,
+                   "hip_graph": ("whole-step graph with parallel branches" if args.whole_step_graph else "three linear recordings (GNN, text encoder per size bucket, head)"
+                                 + (", GNN and encoder replayed on two streams at once" if args.concurrent_graphs else "")) if args.hip_graph else False,
                    "gemm_algorithms": ("library picks from gmlm_amd/tunable/gfx950.csv (TunableOp lookup)" if gemm_tuning and not args.gemm_tune
                                        else "tuned in this run" if gemm_tuning else "library default heuristic"),
                    "loss": round(float(loss.detach()), 5)},

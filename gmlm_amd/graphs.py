@@ -68,7 +68,7 @@ class GraphedStep:
     ``head(gnn_embeds, plm_embeds)`` -> logits; both are autograd-aware graph replays."""
 
     def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-                 encoder: bool = True, whole_step: bool = False):
+                 encoder: bool = True, whole_step: bool = False, concurrent: bool = False):
         if model.dist is not None:
             raise ValueError("hipGraph capture is single-GPU: collectives of the node partition are not captured")
         if not model.training:
@@ -80,6 +80,9 @@ class GraphedStep:
         self.encoder_buckets = 4                         # recordings kept (LRU)
         self._encoders = {}                              # bucket key -> (token set, graphed region)
         self.whole_step = bool(whole_step) and self.encoder_enabled
+        # replay the GNN recording and the encoder recording on two streams at once (model.forward): the recordings themselves
+        # stay linear; the seed bump then happens eagerly AHEAD of the fork instead of inside the GNN recording
+        self.concurrent = bool(concurrent) and self.encoder_enabled and not self.whole_step
         self._steps = {}                                 # bucket key -> (token set, graphed whole-forward region)
         self._side = torch.cuda.Stream(device=dev)
         self._side2 = torch.cuda.Stream(device=dev)
@@ -100,7 +103,7 @@ class GraphedStep:
         gnn_params = _touched_params(model, lambda: gnn_fn(xs).sum().backward())
         head_params = _touched_params(model, lambda: head_fn(gs, ts).sum().backward())
         xs.grad = gs.grad = ts.grad = None
-        regions = (_Region(gnn_fn, gnn_params, self.counter, True), _Region(head_fn, head_params, self.counter, False))
+        regions = (_Region(gnn_fn, gnn_params, self.counter, not self.concurrent), _Region(head_fn, head_params, self.counter, False))
         self.gnn, self.head = torch.cuda.make_graphed_callables(regions, ((xs,), (gs, ts)), num_warmup_iters=2)
 
     def encoder(self, model, key, tokens, tables):
@@ -131,8 +134,6 @@ class GraphedStep:
             edge_index, edge_type = self._graph_args
 
             def step_fn(x, *t):
-                from . import nn as _nn
-                _nn.DCOMP_BY_GEMM = True             # (the backward is recorded right after this forward: see reset below)
                 model._branch_stream = self._side2
                 cur = torch.cuda.current_stream()
                 side.wait_stream(cur)                                        # fork (behind the seed bump of _Region.forward)
@@ -156,11 +157,7 @@ class GraphedStep:
             samples = (xs,) + tuple(t.clone() for t in tables)
             used = _touched_params(model, lambda: step_fn(*samples).sum().backward())
             xs.grad = None
-            from . import nn as _nn
-            try:
-                region = torch.cuda.make_graphed_callables(_Region(step_fn, used, self.counter, True), samples, num_warmup_iters=2)
-            finally:
-                _nn.DCOMP_BY_GEMM = False
+            region = torch.cuda.make_graphed_callables(_Region(step_fn, used, self.counter, True), samples, num_warmup_iters=2)
             while len(self._steps) >= self.encoder_buckets:
                 self._steps.pop(next(iter(self._steps)))
             hit = (tokens, region)
@@ -174,7 +171,7 @@ class GraphedStep:
 
 
 def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-            encoder: bool = True, whole_step: bool = False) -> GraphedStep:
+            encoder: bool = True, whole_step: bool = False, concurrent: bool = False) -> GraphedStep:
     """Record the GNN and head regions for this (soft-masked input shape, graph) and attach them to ``model``:
     ``model.forward`` replays them whenever it is called in training mode with an input of the same shape / dtype and the
     same ``edge_index`` tensor; any other call runs eagerly.  ``encoder``: also record the text encoder, per size bucket, the
@@ -186,6 +183,6 @@ def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type:
     GEMM (``nn.DCOMP_BY_GEMM``), which never showed the effect, but the cause is not understood; the three linear recordings
     replay bit for bit and stay the default.  ``model.release_hip_graphs()`` drops the recordings."""
     model._graphed = None
-    g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder, whole_step)
+    g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder, whole_step, concurrent)
     model._graphed = g
     return g

@@ -22,8 +22,8 @@ from torch.utils.checkpoint import checkpoint
 
 from . import bert, ops
 from .graph import GraphCache, RelCSR
-from .nn import (CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, compute_dtype, cross_attention_specs, linear_specs,
-                 shadow_params, use_shadow)
+from .nn import (SPLITK_ROW_QUANTUM, CrossAttention, GraphNorm, MultiScaleFusion, RGCNConv, _linear, compute_dtype,
+                 cross_attention_specs, linear_specs, shadow_params, use_shadow)
 
 logger = logging.getLogger(__name__)
 
@@ -375,11 +375,13 @@ class GraphTextLM(nn.Module):
                     # variable-length packing: only real tokens exist; index arithmetic from the HOST copy of the
                     # lengths (sizes known without a device sync), token gather on the device
                     total = int(lh.sum())
-                    # large batches: pad the token count to a multiple of 16 with ONE dummy sequence of [PAD] tokens behind the
-                    # real ones (never pooled, zero gradient): the split-K weight-gradient GEMMs then cut T into 16 equal slices
-                    # with no tail rows (a tail is one more tiny GEMM and a full pass over dW per weight: 2 x 48 launches per
-                    # BERT-base step), and every GEMM sees an aligned row count
-                    pad = (-total) % 16 if (total >= 4096 and lmax >= 16) else 0
+                    # large batches: pad the token count to a multiple of 16 (of 112 = lcm(14, 16) once the weight-gradient GEMMs
+                    # slice by 14 or 16: nn._splitk_wgrad) with ONE dummy sequence of [PAD] tokens behind the real ones (never
+                    # pooled, zero gradient): the split-K weight-gradient GEMMs then cut T into equal slices with no tail rows
+                    # (a tail is one more tiny GEMM and a full pass over dW per weight: 2 x 48 launches per BERT-base step),
+                    # and every GEMM sees an aligned row count
+                    quantum = SPLITK_ROW_QUANTUM if (total >= 65536 and lmax >= SPLITK_ROW_QUANTUM) else 16
+                    pad = (-total) % quantum if (total >= 4096 and lmax >= 16) else 0
                     cu_h = torch.zeros(bi.numel() + 1 + (1 if pad else 0), dtype=torch.int32)
                     cu_h[1:bi.numel() + 1] = torch.cumsum(lh, 0)
                     if pad:
@@ -472,6 +474,22 @@ class GraphTextLM(nn.Module):
             if self.active_index is not None:
                 self.active_index.record_stream(cur)
             return self.head(gnn_embeds, plm_embeds)
+        if replay and g.concurrent:
+            # the GNN recording and the encoder recording (or the eager encoder, when the batch needs several micro-batches)
+            # replay on two streams side by side; each recording is the linear one, the head's follows the join
+            cur = torch.cuda.current_stream()
+            side = g._side
+            g.counter.add_(1)                                         # the step's dropout seed, ahead of the fork
+            side.wait_stream(cur)                                     # fork
+            gnn_embeds = g.gnn(gnn_input_features)
+            tokens = self.tokenize(all_node_texts)
+            with torch.cuda.stream(side):                             # issued last: its backward is queued first
+                plm_embeds = self.encode_texts(tokens, text_processing_node_mask, plm_batch_size, mask_copy, None)
+            cur.wait_stream(side)                                     # join
+            plm_embeds.record_stream(cur)
+            if self.active_index is not None:
+                self.active_index.record_stream(cur)
+            return g.head(gnn_embeds, plm_embeds)
         # (a recorded encoder casts the weights inside its own graph)
         weights = None if (replay and g.encoder_enabled) else bert.prepare_weights(self.plm_encoder, self._cd())
         gnn_embeds = g.gnn(gnn_input_features) if replay else \
@@ -486,12 +504,12 @@ class GraphTextLM(nn.Module):
         return self._side_stream
 
     def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True,
-                           whole_step: bool = False):
+                           whole_step: bool = False, concurrent: bool = False):
         """Record the static-shape regions of the training step (GNN blocks + fusion; cross-attention + head) as hipGraphs
         for THIS input shape and ``edge_index`` tensor; ``forward`` then replays them (training mode, same shape, same
         edge tensor) and runs eagerly otherwise.  For the launch-bound small configurations (gmlm_amd/graphs.py)."""
         from . import graphs
-        return graphs.capture(self, gnn_input_sample, edge_index, encoder=encoder, whole_step=whole_step)
+        return graphs.capture(self, gnn_input_sample, edge_index, encoder=encoder, whole_step=whole_step, concurrent=concurrent)
 
     def release_hip_graphs(self):
         self._graphed = None

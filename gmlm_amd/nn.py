@@ -73,6 +73,10 @@ _F32_OUT = [True]          # torch.bmm(..., out_dtype=float32) available (checke
 _F32_MM = [True]           # torch.mm(..., out_dtype=float32) likewise
 
 
+_SLICES_MEASURED = {(2304, 768): 14, (3072, 768): 14, (768, 3072): 14}
+SPLITK_ROW_QUANTUM = 112   # lcm(14, 16): a token count that is a multiple of it leaves no tail rows for either slice count
+
+
 def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor, keep_fp32: bool = False) -> torch.Tensor:
     """dW [N, K] = dy2^T [N, T] @ x2 [T, K] (returned in fp32 when ``keep_fp32``, else in dy2's dtype).  The reduction dim is the token count (10^4..10^5) while the
     output is only a few 256x256 tiles, so one hipBLASLt call leaves most CUs idle; cutting T into S
@@ -83,8 +87,10 @@ def _splitk_wgrad(dy2: torch.Tensor, x2: torch.Tensor, keep_fp32: bool = False) 
     s = 1
     if tiles < 128 and t >= 16384:                    # (node-level layers, t = a few thousand rows: one GEMM; slicing them left a tail GEMM + an add per weight)
         import math
-        # measured on MI355X: 16 slices is within 5 % of the best split for every BERT shape once T >= 64k
-        s = 16 if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
+        # measured on MI355X (tools/ubench/wgrad_shapes.py, T = 91,712): 16 slices is within 5 % of the best power of two for every
+        # BERT shape once T >= 64k; 14 fills the chip better for three of the four BERT-base weights (QKV 322 vs 415 us, FFN
+        # 440 vs 455 and 444 vs 447 us; the 768 x 768 output projection stays at 16: 128 vs 161 us)
+        s = _SLICES_MEASURED.get((n, k), 16) if t >= 65536 else min(16, max(1, 2 ** round(math.log2(200.0 / tiles))))
     if s == 1:
         if keep_fp32 and dy2.dtype != torch.float32 and _F32_MM[0]:
             try:                                          # fp32 result straight out of the GEMM: no cast pass over dW
@@ -339,28 +345,7 @@ class _BasisCompose(torch.autograd.Function):
         ops.check(ops.lib().gmlm_basis_compose_bwd(ops._ptr(comp_a), ops._ptr(weight2d), ops._ptr(dw), ra, nb, cols,
                                                    ops._ptr(dweight), ops._ptr(dcomp), ops._ptr(ws), ws.numel(), ops._stream()),
                   "gmlm_basis_compose_bwd")
-        if DCOMP_BY_GEMM:
-            # see graphs.GraphedStep.step: inside a recording with parallel branches this kernel's dcomp accumulators (108 long-
-            # lived registers per lane) sporadically came out wrong while dweight, from the same loads, was right; the
-            # same product as a GEMM over the tensors in memory never did (24 runs x 8 replays, graph against graph)
-            dcomp = _rowdot_batched(dw, weight2d)
         return dcomp, dweight, None
-
-
-DCOMP_BY_GEMM = False        # set while a branched whole-step hipGraph is recorded (graphs.py)
-
-
-def _rowdot_batched(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """a [R, K] @ b [B, K]^T for tiny R, B and a very long K (K = in * out of an RGCN layer): ONE GEMM with M = 3, N = 30,
-    K = 2 * 10^6 runs on a handful of workgroups; cut K into up to 256 slices, batch them, add the slices (fp32)."""
-    k = a.shape[1]
-    s = 256
-    while s > 1 and (k % s or k // s < 512):
-        s //= 2
-    if s == 1:
-        return a @ b.t()
-    prod = torch.bmm(a.view(a.shape[0], s, k // s).transpose(0, 1), b.view(b.shape[0], s, k // s).permute(1, 2, 0))   # [s, R, B]
-    return prod.sum(0)
 
 
 class RGCNConv(nn.Module):

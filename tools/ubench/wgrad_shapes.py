@@ -1,10 +1,11 @@
 """Split-K weight-gradient GEMM forms for the BERT shapes of the bench (T = 91,698 tokens, S = 16 slices):
 fp32-output batched GEMM (what bert._splitk_wgrad issues; not covered by TunableOp) against the bf16-output batched form
-that TunableOp can tune.  usage: [PYTORCH_TUNABLEOP_ENABLED=1] python tools/ubench/wgrad_shapes.py"""
+that TunableOp can tune.  usage: [PYTORCH_TUNABLEOP_ENABLED=1] python tools/ubench/wgrad_shapes.py [S,S,...]"""
 import torch
 dev = torch.device("cuda")
 import sys
 T = 91712
+SLICES = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (8, 16, 32)
 
 def timeit(f, n=20):
     for _ in range(3): f()
@@ -18,7 +19,7 @@ def timeit(f, n=20):
 for name, n, k in (("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)):
   dy = torch.randn(T, n, device=dev, dtype=torch.bfloat16)
   x = torch.randn(T, k, device=dev, dtype=torch.bfloat16)
-  for S in (8, 16, 32):
+  for S in SLICES:
     q = T // S
     a = dy[:S * q].view(S, q, n).transpose(1, 2)
     b = x[:S * q].view(S, q, k)
