@@ -529,7 +529,8 @@ def main():
     ap.add_argument("--no-encoder-graph", action="store_true", help="with hipGraphs: leave the text encoder eager (GNN + head regions only)")
     ap.add_argument("--overlap-streams", action="store_true", help="text encoder on a second HIP stream beside the GNN (model.overlap_streams)")
     ap.add_argument("--concurrent-graphs", action="store_true", help="with hipGraphs: replay the (linear) GNN and encoder recordings on two streams at once")
-    ap.add_argument("--whole-step-graph", action="store_true", help="with hipGraphs: ONE graph per step with the encoder and GNN branches side by side instead of three linear recordings (faster; opt-in, see graphs.capture)")
+    ap.add_argument("--whole-step-graph", action="store_true", help="(default with hipGraphs) ONE graph per step with the encoder and GNN branches side by side")
+    ap.add_argument("--linear-graphs", action="store_true", help="with hipGraphs: three linear recordings (GNN, encoder per size bucket, head) instead of the whole-step graph")
     ap.add_argument("--host-profile", default=None, metavar="FILE", help="cProfile the timed steps (host side) and write the top entries to FILE")
     ap.add_argument("--no-kernel-timers", action="store_true")
     ap.add_argument("--no-micro", action="store_true", help="skip the kernel micro-benchmarks (rank 0, N=1 only)")
@@ -613,6 +614,7 @@ def main():
     if args.hip_graph:
         if distributed:
             raise SystemExit("--hip-graph is single-GPU")
+        args.whole_step_graph = not (args.linear_graphs or args.concurrent_graphs or args.no_encoder_graph)
         model.capture_hip_graphs(model.soft_mask_input(x, active, 0.7), ei, encoder=not args.no_encoder_graph,
                                  whole_step=args.whole_step_graph, concurrent=args.concurrent_graphs)
 

@@ -68,7 +68,7 @@ class GraphedStep:
     ``head(gnn_embeds, plm_embeds)`` -> logits; both are autograd-aware graph replays."""
 
     def __init__(self, model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-                 encoder: bool = True, whole_step: bool = False, concurrent: bool = False):
+                 encoder: bool = True, whole_step: bool = True, concurrent: bool = False):
         if model.dist is not None:
             raise ValueError("hipGraph capture is single-GPU: collectives of the node partition are not captured")
         if not model.training:
@@ -171,17 +171,18 @@ class GraphedStep:
 
 
 def capture(model, xm_sample: torch.Tensor, edge_index: torch.Tensor, edge_type: Optional[torch.Tensor] = None,
-            encoder: bool = True, whole_step: bool = False, concurrent: bool = False) -> GraphedStep:
+            encoder: bool = True, whole_step: bool = True, concurrent: bool = False) -> GraphedStep:
     """Record the GNN and head regions for this (soft-masked input shape, graph) and attach them to ``model``:
     ``model.forward`` replays them whenever it is called in training mode with an input of the same shape / dtype and the
     same ``edge_index`` tensor; any other call runs eagerly.  ``encoder``: also record the text encoder, per size bucket, the
-    first time a step needs that bucket; ``whole_step`` (opt-in): record encoder + GNN + head as ONE graph per bucket whose
-    encoder and GNN branches run side by side (``GraphedStep.step``; a step whose text batch needs several micro-batches falls
-    back to the separate regions).  Opt-in because of an open issue: with branches, about one step in thirty returned ONE small
-    gradient tensor (``rgcn4.comp``, 5 x 30) off by up to 1 % - the basis-composition backward kernel wrote wrong per-block
-    partial sums from inputs that were right.  Inside such a recording that product is now formed by a
-    GEMM (``nn.DCOMP_BY_GEMM``), which never showed the effect, but the cause is not understood; the three linear recordings
-    replay bit for bit and stay the default.  ``model.release_hip_graphs()`` drops the recordings."""
+    first time a step needs that bucket; ``whole_step`` (default): record encoder + GNN + head as ONE graph per bucket whose
+    encoder and GNN branches (and the second CrossAttention) run side by side (``GraphedStep.step``; a step whose text batch
+    needs several micro-batches falls back to the separate regions); ``whole_step=False``: three linear recordings replayed one
+    after the other, or - ``concurrent`` - GNN and encoder recordings replayed on two streams at once.  Every mode returns the
+    eager step's logits and gradients bit for bit (tests/test_gpu_graphs.py; 800-step soaks per mode with
+    tools/dev/replay_diff.py).  (Rounds 2-3 carried an open issue here: with two streams busy, ``rgcn4.comp``'s gradient came
+    out wrong in about one step of thirty.  Cause: packed-fp32 code that the SLP vectoriser made of the basis backward kernel's
+    accumulation - csrc/Makefile)  ``model.release_hip_graphs()`` drops the recordings."""
     model._graphed = None
     g = GraphedStep(model, xm_sample, edge_index, edge_type, encoder, whole_step, concurrent)
     model._graphed = g

@@ -504,7 +504,7 @@ class GraphTextLM(nn.Module):
         return self._side_stream
 
     def capture_hip_graphs(self, gnn_input_sample: torch.Tensor, edge_index: torch.Tensor, encoder: bool = True,
-                           whole_step: bool = False, concurrent: bool = False):
+                           whole_step: bool = True, concurrent: bool = False):
         """Record the static-shape regions of the training step (GNN blocks + fusion; cross-attention + head) as hipGraphs
         for THIS input shape and ``edge_index`` tensor; ``forward`` then replays them (training mode, same shape, same
         edge tensor) and runs eagerly otherwise.  For the launch-bound small configurations (gmlm_amd/graphs.py)."""
