@@ -266,3 +266,24 @@ def test_stream_overlap_changes_nothing(dev, cd):
         assert set(g0) == set(g1)
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("mode", ["concurrent", "whole"])
+def test_recorded_modes_fall_back_when_the_text_batch_needs_micro_batches(dev, mode):
+    """A step whose active texts do not fit one micro-batch cannot replay a recorded encoder: the whole-step mode then replays
+    the GNN and head recordings around an eager encoder, the concurrent mode runs that eager encoder on the second stream beside
+    the GNN recording.  Same logits and gradients as the eager model, bit for bit; a later step that fits replays again."""
+    cfg = _cfg(0.0)
+    x, ei, y, tokens, masks = _data(cfg, dev)
+    eager = build_model(cfg, dev, compute_dtype=torch.bfloat16).train()
+    graphed = build_model(cfg, dev, compute_dtype=torch.bfloat16).train()
+    g = graphed.capture_hip_graphs(graphed.soft_mask_input(x, masks[0], 0.7), ei, whole_step=mode == "whole",
+                                   concurrent=mode == "concurrent")
+    for mask, pb in ((masks[0], 64), (masks[1], 64), (masks[0], 512), (masks[2], 64)):
+        eager.plm_bucketed = pb == 512                                   # the recorded encoder works on the bucket-padded batch
+        l0, g0 = _step(eager, x, ei, y, tokens, mask, pb)
+        l1, g1 = _step(graphed, x, ei, y, tokens, mask, pb)
+        assert torch.equal(l0, l1)
+        assert set(g0) == set(g1)
+        _same_gradients(g0, g1)
+    assert len(g._encoders) + len(g._steps) >= 1
