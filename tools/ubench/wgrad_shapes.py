@@ -1,10 +1,11 @@
 """Split-K weight-gradient GEMM forms for the BERT shapes of the bench (T = 91,698 tokens, S = 16 slices):
 fp32-output batched GEMM (what bert._splitk_wgrad issues; not covered by TunableOp) against the bf16-output batched form
-that TunableOp can tune.  usage: [PYTORCH_TUNABLEOP_ENABLED=1] python tools/ubench/wgrad_shapes.py [S,S,...]"""
+that TunableOp can tune.  usage: [PYTORCH_TUNABLEOP_ENABLED=1] [T=tokens] [GEOMETRY=base|mini] python tools/ubench/wgrad_shapes.py [S,S,...]"""
 import torch
 dev = torch.device("cuda")
 import sys
-T = 91712
+import os
+T = int(os.environ.get("T", "91712"))
 SLICES = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else (8, 16, 32)
 
 def timeit(f, n=20):
@@ -16,7 +17,9 @@ def timeit(f, n=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for name, n, k in (("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)):
+SHAPES = {"base": (("qkv", 2304, 768), ("o", 768, 768), ("ffn1", 3072, 768), ("ffn2", 768, 3072)),
+          "mini": (("qkv", 768, 256), ("o", 256, 256), ("ffn1", 1024, 256), ("ffn2", 256, 1024))}[os.environ.get("GEOMETRY", "base")]   # BERT-base / BERT-mini (Chameleon-size workload)
+for name, n, k in SHAPES:
   dy = torch.randn(T, n, device=dev, dtype=torch.bfloat16)
   x = torch.randn(T, k, device=dev, dtype=torch.bfloat16)
   for S in SLICES:
