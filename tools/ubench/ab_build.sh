@@ -6,7 +6,7 @@ cd "$(dirname "$0")/../.."
 name=$1; shift
 out=build/ab/$name
 mkdir -p $out/gmlm_amd $out/tools/ubench
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Iinclude -mllvm -amdgpu-mfma-vgpr-form $*"
+F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fno-slp-vectorize -Iinclude -mllvm -amdgpu-mfma-vgpr-form $*"
 /opt/rocm/bin/hipcc $F -c gmlm_amd/csrc/attn_kernels.hip -o $out/attn_kernels.o &
 /opt/rocm/bin/hipcc $F -fno-slp-vectorize -c gmlm_amd/csrc/attn_fwd_pipe.hip -o $out/attn_fwd_pipe.o &
 /opt/rocm/bin/hipcc $F -c gmlm_amd/csrc/attn_short.hip -o $out/attn_short.o &
